@@ -1,0 +1,86 @@
+/* libsimseg_hip.so -- C ABI of the MI355X-native SimSeg hot path (gfx950 only).
+ *
+ * The reference (muyangyi/SimSeg) has no native boundary: its hot path is torch/timm/HF Python.  This header is
+ * the boundary our Python mirror of `simseg.models` binds through ctypes; each entry point names the reference
+ * code it replaces (paths relative to /root/reference, or the third-party module the reference calls).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch-ROCm tensors); the library never
+ *     allocates, frees or retains device memory;
+ *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); nothing synchronises;
+ *   - return 0 on success, negative on error; the message is in simseg_last_error() (thread-local);
+ *   - dtype codes: 0 = fp32, 1 = bf16.  Matrices are row-major.
+ */
+#ifndef SIMSEG_HIP_H
+#define SIMSEG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int simseg_version(void);
+const char* simseg_last_error(void);
+
+/* C[M,N] = epilogue(alpha * opA(A) . opB(B)).  transA=0: A is [M,K]; 1: [K,M].  transB=0: B is [N,K] (nn.Linear
+ * weight layout); 1: [K,N].  Epilogue order: *rowscale[row], +bias[col], (save pre-activation to aux_out),
+ * act (1 = erf-GELU, 2 = multiply by GELU'(aux)), dropout(p, seed), +residual.  row_group=G>0 writes row r to
+ * (r/G)*(G+1)+1+r%G (ViT patch rows behind [cls]); res_mod reads the residual at row 1+r%G (pos_embed).
+ * splitk>1 accumulates fp32 partials atomically into C (C must hold the value to accumulate onto).
+ * Replaces: nn.Linear inside timm Block / HF BertLayer (called via simseg/models/backbones/mml/vit_builder.py:18,
+ * huggingface_builder.py:16-17), Conv2d patch embed (vit_builder.py:14), SimpleProjection
+ * (simseg/models/components/projection.py:45-46), the logits matmul (simseg/models/criteria/losses/mml_loss.py:73),
+ * the patch x text contraction (tools/seg_evaluation.py:136) and emb_sim (simseg/tasks/clip/hooks/utils.py:36). */
+int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                int64_t ldc, int in_dtype, int out_dtype, int transA, int transB, float alpha, const float* bias,
+                const float* rowscale, const float* residual, int64_t ldr, int act, const void* aux, void* aux_out,
+                int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, void* stream);
+
+/* LayerNorm over the last dim of x[rows,D] (fp32 residual stream) -> y (out_dtype) and optionally a bf16 copy.
+ * Saves mean/rstd when non-null.  Replaces nn.LayerNorm in timm Block.norm1/norm2/VisionTransformer.norm
+ * (eps 1e-6) and HF Bert*Output.LayerNorm / BertEmbeddings.LayerNorm (eps 1e-12). */
+int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_dtype, void* y_bf16,
+                         float* mean, float* rstd, int64_t rows, int64_t D, float eps, void* stream);
+/* dx = LN'(dy_bf16 + dy_f32) + dres; writes dx_f32 and/or dx_bf16; dgamma/dbeta are ACCUMULATED. */
+int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x, const float* mean,
+                         const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
+                         float* dbeta, int64_t rows, int64_t D, void* stream);
+
+/* out[n] += sum_r in[r,n]  (bias / embedding-table gradients). */
+int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream);
+
+/* timm PatchEmbed (Conv2d 3->D, k16 s16) as a GEMM: gathers image[B,3,H,W] into cols[B*N,768] in (c,kh,kw) order. */
+int simseg_vit_im2col(const float* image, void* cols, int out_dtype, int64_t B, int64_t H, int64_t W, void* stream);
+/* x[b,0,:] = cls + pos[0] (vit_builder.py:15-17) and its gradient dcls += sum_b dx[b,0,:]. */
+int simseg_vit_cls_rows(const float* cls, const float* pos, float* x, int64_t B, int64_t T, int64_t D, void* stream);
+int simseg_vit_cls_grad(const float* dx, float* dcls, int64_t B, int64_t T, int64_t D, void* stream);
+
+/* HF BertEmbeddings: out[b,l,:] = word[ids[b,l]] + pos[l] + type[0] (LayerNorm is a separate call).
+ * bwd: dword[ids] += dsum for unmasked tokens (masked tokens carry an exactly-zero gradient). */
+int simseg_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, float* out,
+                          int64_t B, int64_t L, int64_t D, int64_t vocab, void* stream);
+int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, const float* dsum, float* dword, int64_t B, int64_t L,
+                          int64_t D, int64_t vocab, void* stream);
+
+/* LoDA pooling + L2norm: emb[b,:] = l2norm(mean over the k largest tokens per channel) with the reference's
+ * -10000 overwrite of masked tokens.  simseg/models/components/pooling.py:52-65 + normalization.py:6-11
+ * (pipelines/clip.py:87-93,111-120).  idx[B,k,P] and norm[B] are saved for the backward. */
+int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
+                                int64_t B, int64_t N, int64_t P, int k, float eps, void* stream);
+int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
+                                int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, void* stream);
+
+/* rnorm[r] = 1 / max(||x_r||_2, eps): the F.normalize of tools/seg_evaluation.py:112 as a GEMM row scale. */
+int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t rows, int64_t D, float eps, void* stream);
+
+int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
+int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);
+/* g[i] = keep(seed, i) ? g[i] / (1-p) : 0 -- regenerates the forward dropout mask of simseg_gemm for the backward. */
+int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream);
+
+/* hardware probe used by tests: lane/element map of ds_read_b64_tr_b16. */
+int simseg_debug_tr16_probe(int* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+// Shared device/host helpers for libsimseg_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ---- error plumbing (no exceptions cross the C ABI) -------------------------------------------
+extern thread_local char g_simseg_err[512];
+int simseg_set_error(const char* fmt, ...);
+
+#define SS_CHECK(cond, ...)                          \
+    do {                                             \
+        if (!(cond)) return simseg_set_error(__VA_ARGS__); \
+    } while (0)
+
+#define SS_LAUNCH_CHECK(name)                                                         \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) return simseg_set_error("%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- numeric helpers --------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per element index, reproducible in backward
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// keep-probability test: keep iff hash >= p * 2^32
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    return hash_u32(seed, idx) >= thresh;
+}
+
+// XCD-aware, bijective block remap: XCD x (= bid % 8, observed dispatch) gets a contiguous chunk of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + j;
+}

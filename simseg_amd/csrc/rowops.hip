@@ -1,0 +1,579 @@
+// HBM-bound row kernels of the encoder path: LayerNorm fwd/bwd (K3), patch gather (K1), [cls]+pos rows (K2),
+// BERT embedding gather/scatter (K9), LoDA top-k pooling + L2norm fwd/bwd (K11, K12), row norms, column sums,
+// casts and transposes.  Every kernel moves 16 bytes per lane per access and reduces rows with wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 8;   // float4 chunks per lane -> D <= 2048
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <typename TI> __device__ __forceinline__ void load4(const TI* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row.  x fp32 (residual stream) -> y (TO) [+ optional bf16 copy y2]
+// timm Block.norm1/norm2/norm (eps 1e-6), HF BertSelfOutput/BertOutput/BertEmbeddings LayerNorm (eps 1e-12)
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TO* __restrict__ y,
+                                                     bf16_t* __restrict__ y2, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = D >> 2;
+    const float* xr = x + (long)row * D;
+    float v[LN_MAXC][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            load4<float>(xr + c * 4, v[i]);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float g[4], b[4], o[4];
+            load4<float>(gamma + c * 4, g);
+            load4<float>(beta + c * 4, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            store4<TO>(y + (long)row * D + c * 4, o);
+            if (y2) store4<bf16_t>(y2 + (long)row * D + c * 4, o);
+        }
+    }
+}
+
+// LayerNorm backward.  dy = dy16 (bf16, optional) + dy32 (fp32, optional);  dx = ln_bwd(dy) + dres (optional)
+// Writes dx32 (fp32 residual-gradient stream) and dx16 (bf16 copy fed to the next dgrad/wgrad GEMMs);
+// dgamma/dbeta are accumulated with one atomic per column per block.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
+                                                     const float* __restrict__ dres, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx32,
+                                                     bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int D) {
+    __shared__ float red[2][1024];   // [dgamma|dbeta][wave * 256 + lane * 4 + j]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    float ag[LN_MAXC][4], ab[LN_MAXC][4], gm[LN_MAXC][4];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = 0.f; }
+        const int c = lane + 64 * i;
+        if (c < nch) load4<float>(gamma + c * 4, gm[i]);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXC][4], xh[LN_MAXC][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const long o = (long)row * D + c * 4;
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4];
+                if (dy16) load4<bf16_t>(dy16 + o, a);
+                if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
+                load4<float>(x + o, xv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    ag[i][j] += a[j] * xh[i][j];
+                    ab[i][j] += a[j];
+                    g[i][j] = a[j] * gm[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const long o = (long)row * D + c * 4;
+                float out[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (dres) load4<float>(dres + o, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + r[j];
+                if (dx32) store4<float>(dx32 + o, out);
+                if (dx16) store4<bf16_t>(dx16 + o, out);
+            }
+        }
+    }
+    // cross-wave reduction of the column partials, then one atomic per column per block
+    float* rg = red[0];
+    float* rb = red[1];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        __syncthreads();
+        if (c < nch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rg[wave * 256 + lane * 4 + j] = ag[i][j]; rb[wave * 256 + lane * 4 + j] = ab[i][j]; }
+        }
+        __syncthreads();
+        if (wave == 0 && c < nch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sg = 0.f, sb = 0.f;
+                for (int w = 0; w < 4; ++w) { sg += rg[w * 256 + lane * 4 + j]; sb += rb[w * 256 + lane * 4 + j]; }
+                atomicAdd(dgamma + c * 4 + j, sg);
+                atomicAdd(dbeta + c * 4 + j, sb);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums  out[n] += sum_r in[r, n]   (bias gradients, token-type / position embedding gradients)
+// block = 32 column-chunks (8 columns each) x 8 row lanes
+// ---------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, float* __restrict__ out, long rows, int N,
+                                                     long ld, int rows_per_block) {
+    __shared__ float red[8][32][8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + tx) * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (col < N) {
+        for (long r = r0 + ty; r < r1; r += 8) {
+            float a[4], b[4];
+            load4<TI>(in + r * ld + col, a);
+            load4<TI>(in + r * ld + col + 4, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
+    __syncthreads();
+    if (ty == 0 && col < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+            for (int w = 0; w < 8; ++w) s += red[w][tx][j];
+            atomicAdd(out + col + j, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ViT patch gather (timm PatchEmbed Conv2d k16 s16 as a GEMM): image [B,3,H,W] fp32 -> cols [B*N, 768],
+// column order (c, kh, kw) = flattened Conv2d weight [D,3,16,16].  One thread per 4 consecutive kw.
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void im2col_kernel(const float* __restrict__ img, TO* __restrict__ cols, int B, int H, int W) {
+    const int gw = W >> 4, gh = H >> 4;
+    const long total = (long)B * gh * gw * 192;   // 768 / 4 chunks per patch
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 192);
+        const long pr = i / 192;                  // patch row index b * N + ph * gw + pw
+        const int pw = (int)(pr % gw);
+        const int ph = (int)((pr / gw) % gh);
+        const int b = (int)(pr / ((long)gw * gh));
+        const int c = ch >> 6, kh = (ch >> 2) & 15, kw = (ch & 3) * 4;
+        float v[4];
+        load4<float>(img + (((long)b * 3 + c) * H + ph * 16 + kh) * W + pw * 16 + kw, v);
+        store4<TO>(cols + pr * 768 + ch * 4, v);
+    }
+}
+
+// x[b, 0, :] = cls + pos[0]   (vit_builder.py:15-17; the patch rows are written by the patch GEMM epilogue)
+__global__ void vit_cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                                    int B, int T, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i % D;
+    x[(long)b * T * D + d] = cls[d] + pos[d];
+}
+// backward: dcls += sum_b dx[b,0,:],  dpos[0] handled by the position column-sum over all rows
+__global__ void vit_cls_grad_kernel(const float* __restrict__ dx, float* __restrict__ dcls, int B, int T, int D) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(long)b * T * D + d];
+    dcls[d] += s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BERT embeddings (HF BertEmbeddings): sum[b,l,:] = word[id] + pos[l] + type[0]     (LayerNorm runs next)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bert_embed_kernel(const long* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ type0,
+                                                         float* __restrict__ out, int rows, int L, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int l = row % L;
+    for (int c = lane; c < (D >> 2); c += 64) {
+        float a[4], b[4], t[4], o[4];
+        load4<float>(word + id * D + c * 4, a);
+        load4<float>(pos + (long)l * D + c * 4, b);
+        load4<float>(type0 + c * 4, t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a[j] + t[j] + b[j];
+        store4<float>(out + (long)row * D + c * 4, o);
+    }
+}
+// backward: dword[id] += dsum[row] for valid (unmasked) tokens.  Masked tokens carry an exactly-zero gradient
+// (they are masked as keys and overwritten before pooling), so they are skipped.
+__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const long* __restrict__ ids, const long* __restrict__ mask,
+                                                             const float* __restrict__ dsum, float* __restrict__ dword,
+                                                             int rows, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    if (mask && mask[row] == 0) return;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int c = lane; c < D; c += 64) atomicAdd(dword + id * D + c, dsum[(long)row * D + c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LoDA top-k pooling + L2norm  (components/pooling.py:52-65 + normalization.py:6-11)
+// tok [B,N,P] -> emb [B,P] = l2norm(mean of the k largest over tokens, per channel).  Block per batch row,
+// one thread per channel (coalesced across channels), top-k kept sorted in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int POOL_MAXK = 8;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += sh[i];
+    return s;
+}
+
+template <typename TI>
+__global__ void topk_pool_fwd_kernel(const TI* __restrict__ tok, const long* __restrict__ mask, float* __restrict__ emb,
+                                     int* __restrict__ idx, float* __restrict__ norm_out, int N, int P, int k, float eps) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x, c = threadIdx.x;
+    float tv[POOL_MAXK];
+    int ti[POOL_MAXK];
+#pragma unroll
+    for (int j = 0; j < POOL_MAXK; ++j) { tv[j] = -INFINITY; ti[j] = 0; }
+    const TI* base = tok + (long)b * N * P + c;
+    for (int n = 0; n < N; ++n) {
+        float v = (float)base[(long)n * P];
+        if (mask && mask[(long)b * N + n] == 0) v = -10000.f;        // pooling.py:60
+        if (v > tv[k - 1]) {
+            // insertion into the descending list (static indexing keeps tv/ti in registers)
+            float cv = v; int ci = n;
+#pragma unroll
+            for (int j = 0; j < POOL_MAXK; ++j) {
+                if (j < k && cv > tv[j]) { const float t = tv[j]; const int u = ti[j]; tv[j] = cv; ti[j] = ci; cv = t; ci = u; }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < POOL_MAXK; ++j) if (j < k) { s += tv[j]; idx[((long)b * k + j) * P + c] = ti[j]; }
+    const float pooled = s / k;
+    const float nrm = sqrtf(block_sum(pooled * pooled, sh));
+    emb[(long)b * P + c] = pooled / (nrm + eps);
+    if (c == 0) norm_out[b] = nrm;
+}
+
+// backward: demb [B,P] -> dtok [B,N,P] (dense, zero off the selected tokens)
+template <typename TO>
+__global__ void topk_pool_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ emb,
+                                     const float* __restrict__ norm, const int* __restrict__ idx, TO* __restrict__ dtok,
+                                     int N, int P, int k, float eps) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float g = demb[(long)b * P + c], y = emb[(long)b * P + c];
+    const float n = norm[b];
+    const float dot = block_sum(g * y, sh);
+    // y = x / (n + eps):  dx = [g - y (g.y)(n+eps)/n] / (n+eps)
+    const float dx = (g - y * dot * (n + eps) / fmaxf(n, 1e-30f)) / (n + eps) / k;
+    int sel[POOL_MAXK];
+#pragma unroll
+    for (int j = 0; j < POOL_MAXK; ++j) sel[j] = j < k ? idx[((long)b * k + j) * P + c] : -1;
+    TO* base = dtok + (long)b * N * P + c;
+    for (int n_ = 0; n_ < N; ++n_) {
+        bool hit = false;
+#pragma unroll
+        for (int j = 0; j < POOL_MAXK; ++j) hit |= (sel[j] == n_);
+        base[(long)n_ * P] = (TO)(hit ? dx : 0.f);
+    }
+}
+
+// rnorm[row] = 1 / max(||x_row||, eps)   (F.normalize, tools/seg_evaluation.py:112); one wave per row
+template <typename TI>
+__global__ __launch_bounds__(256) void row_rnorm_kernel(const TI* __restrict__ x, float* __restrict__ rn, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < (D >> 2); c += 64) {
+        float v[4];
+        load4<TI>(x + row * D + c * 4, v);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) rn[row] = 1.0f / fmaxf(sqrtf(s), eps);
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        load4<float>(in + i * 4, v);
+        store4<bf16_t>(out + i * 4, v);
+    }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float v[4];
+        load4<bf16_t>(in + i * 4, v);
+        store4<float>(out + i * 4, v);
+    }
+}
+
+// out[c, r] = in[r, c]  (fp32, 32x32 LDS tiles)
+__global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) t[j][tx] = in[(long)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(long)(c0 + j) * R + r0 + tx] = t[tx][j];
+}
+
+// in-place dropout mask re-application for backward: g[i] = keep(i) ? g[i] * scale : 0
+template <typename T>
+__global__ void dropout_apply_kernel(T* __restrict__ g, long n, unsigned long long seed, unsigned int thresh, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        g[i] = (T)(dropout_keep(seed, (unsigned long long)i, thresh) ? (float)g[i] * scale : 0.f);
+}
+
+inline int grid_for(long n, int block, int cap = 4096) {
+    long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+
+extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
+                                    void* y_bf16, float* mean, float* rstd, int64_t rows, int64_t D, float eps, void* stream) {
+    SS_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_fwd: D=%lld must be a multiple of 4 and <= %d", (long long)D, LN_MAXC * 256);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, STREAM, x, gamma, beta, (float*)y, (bf16_t*)y_bf16, mean, rstd, (int)rows, (int)D, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, STREAM, x, gamma, beta, (bf16_t*)y, (bf16_t*)y_bf16, mean, rstd, (int)rows, (int)D, eps);
+    SS_LAUNCH_CHECK("layernorm_fwd");
+    return 0;
+}
+
+extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x,
+                                    const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
+                                    float* dgamma, float* dbeta, int64_t rows, int64_t D, void* stream) {
+    SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
+    SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
+    if (rows <= 0) return 0;
+    const int grid = grid_for(rows, 4, 1024);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, x, mean, rstd, gamma,
+                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, (int)rows, (int)D);
+    SS_LAUNCH_CHECK("layernorm_bwd");
+    return 0;
+}
+
+extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream) {
+    SS_CHECK(in && out, "colsum: null pointer");
+    SS_CHECK(N % 8 == 0 && ld % 8 == 0, "colsum: N and ld must be multiples of 8");
+    if (rows <= 0) return 0;
+    int chunks = (int)((rows + 255) / 256);
+    if (chunks > 512) chunks = 512;
+    const int rpb = (int)((rows + chunks - 1) / chunks);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+    if (in_dtype == 0)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, STREAM, (const float*)in, out, (long)rows, (int)N, (long)ld, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, STREAM, (const bf16_t*)in, out, (long)rows, (int)N, (long)ld, rpb);
+    SS_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int simseg_vit_im2col(const float* image, void* cols, int out_dtype, int64_t B, int64_t H, int64_t W, void* stream) {
+    SS_CHECK(image && cols, "im2col: null pointer");
+    SS_CHECK(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "im2col: H, W must be multiples of the 16x16 patch");
+    const long total = B * (H / 16) * (W / 16) * 192;
+    if (total <= 0) return 0;
+    const int grid = grid_for(total, 256, 8192);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, STREAM, image, (float*)cols, (int)B, (int)H, (int)W);
+    else
+        hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, STREAM, image, (bf16_t*)cols, (int)B, (int)H, (int)W);
+    SS_LAUNCH_CHECK("im2col");
+    return 0;
+}
+
+extern "C" int simseg_vit_cls_rows(const float* cls, const float* pos, float* x, int64_t B, int64_t T, int64_t D, void* stream) {
+    SS_CHECK(cls && pos && x, "vit_cls_rows: null pointer");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(vit_cls_rows_kernel, dim3((unsigned)((B * D + 255) / 256)), dim3(256), 0, STREAM, cls, pos, x, (int)B, (int)T, (int)D);
+    SS_LAUNCH_CHECK("vit_cls_rows");
+    return 0;
+}
+
+extern "C" int simseg_vit_cls_grad(const float* dx, float* dcls, int64_t B, int64_t T, int64_t D, void* stream) {
+    SS_CHECK(dx && dcls, "vit_cls_grad: null pointer");
+    hipLaunchKernelGGL(vit_cls_grad_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, STREAM, dx, dcls, (int)B, (int)T, (int)D);
+    SS_LAUNCH_CHECK("vit_cls_grad");
+    return 0;
+}
+
+extern "C" int simseg_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, float* out,
+                                     int64_t B, int64_t L, int64_t D, int64_t vocab, void* stream) {
+    SS_CHECK(ids && word && pos && type0 && out, "bert_embed_fwd: null pointer");
+    SS_CHECK(D % 4 == 0, "bert_embed_fwd: D must be a multiple of 4");
+    const long rows = B * L;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(bert_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, STREAM, (const long*)ids, word, pos, type0, out,
+                       (int)rows, (int)L, (int)D, (int)vocab);
+    SS_LAUNCH_CHECK("bert_embed_fwd");
+    return 0;
+}
+
+extern "C" int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, const float* dsum, float* dword, int64_t B,
+                                     int64_t L, int64_t D, int64_t vocab, void* stream) {
+    SS_CHECK(ids && dsum && dword, "bert_embed_bwd: null pointer");
+    const long rows = B * L;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, STREAM, (const long*)ids, (const long*)mask, dsum,
+                       dword, (int)rows, (int)D, (int)vocab);
+    SS_LAUNCH_CHECK("bert_embed_bwd");
+    return 0;
+}
+
+extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
+                                           int64_t B, int64_t N, int64_t P, int k, float eps, void* stream) {
+    SS_CHECK(tok && emb && idx && norm, "topk_pool_fwd: null pointer");
+    SS_CHECK(P % 64 == 0 && P <= 1024, "topk_pool_fwd: P=%lld must be a multiple of 64 and <= 1024", (long long)P);
+    SS_CHECK(k >= 1 && k <= POOL_MAXK && k <= N, "topk_pool_fwd: k=%d out of range (1..%d, <= N)", k, POOL_MAXK);
+    if (B <= 0) return 0;
+    if (dtype == 0)
+        hipLaunchKernelGGL(topk_pool_fwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const float*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps);
+    else
+        hipLaunchKernelGGL(topk_pool_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const bf16_t*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps);
+    SS_LAUNCH_CHECK("topk_pool_fwd");
+    return 0;
+}
+
+extern "C" int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
+                                           int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, void* stream) {
+    SS_CHECK(demb && emb && norm && idx && dtok, "topk_pool_bwd: null pointer");
+    SS_CHECK(P % 64 == 0 && P <= 1024 && k >= 1 && k <= POOL_MAXK, "topk_pool_bwd: bad P/k");
+    if (B <= 0) return 0;
+    if (dtype == 0)
+        hipLaunchKernelGGL(topk_pool_bwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (float*)dtok, (int)N, (int)P, k, eps);
+    else
+        hipLaunchKernelGGL(topk_pool_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (bf16_t*)dtok, (int)N, (int)P, k, eps);
+    SS_LAUNCH_CHECK("topk_pool_bwd");
+    return 0;
+}
+
+extern "C" int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t rows, int64_t D, float eps, void* stream) {
+    SS_CHECK(x && rnorm, "row_rnorm: null pointer");
+    SS_CHECK(D % 4 == 0, "row_rnorm: D must be a multiple of 4");
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == 0)
+        hipLaunchKernelGGL(row_rnorm_kernel<float>, grid, dim3(256), 0, STREAM, (const float*)x, rnorm, (long)rows, (int)D, eps);
+    else
+        hipLaunchKernelGGL(row_rnorm_kernel<bf16_t>, grid, dim3(256), 0, STREAM, (const bf16_t*)x, rnorm, (long)rows, (int)D, eps);
+    SS_LAUNCH_CHECK("row_rnorm");
+    return 0;
+}
+
+extern "C" int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream) {
+    SS_CHECK(in && out, "cast: null pointer");
+    SS_CHECK(n % 4 == 0, "cast: element count must be a multiple of 4");
+    if (n <= 0) return 0;
+    const int grid = grid_for(n / 4, 256, 8192);
+    if (to_bf16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, STREAM, (const float*)in, (bf16_t*)out, (long)(n / 4));
+    else
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)in, (float*)out, (long)(n / 4));
+    SS_LAUNCH_CHECK("cast");
+    return 0;
+}
+
+extern "C" int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream) {
+    SS_CHECK(in && out, "transpose: null pointer");
+    if (R <= 0 || C <= 0) return 0;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, STREAM, in, out, (int)R, (int)C);
+    SS_LAUNCH_CHECK("transpose");
+    return 0;
+}
+
+extern "C" int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream) {
+    SS_CHECK(g, "dropout_apply: null pointer");
+    SS_CHECK(p >= 0.f && p < 1.f, "dropout_apply: p out of range");
+    if (n <= 0 || p == 0.f) return 0;
+    const unsigned int thresh = (unsigned int)((double)p * 4294967296.0);
+    const float scale = 1.0f / (1.0f - p);
+    const int grid = grid_for(n, 256, 8192);
+    if (dtype == 0)
+        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(grid), dim3(256), 0, STREAM, (float*)g, (long)n, (unsigned long long)seed, thresh, scale);
+    else
+        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, STREAM, (bf16_t*)g, (long)n, (unsigned long long)seed, thresh, scale);
+    SS_LAUNCH_CHECK("dropout_apply");
+    return 0;
+}

@@ -1,0 +1,76 @@
+"""ctypes binding of libsimseg_hip.so.  Prototypes are parsed from include/simseg_hip.h so that the header is the
+single source of truth for the C ABI.  There is no CPU fallback: `call()` raises if the library is missing."""
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "include", "simseg_hip.h")
+LIB_PATH = os.path.join(HERE, "libsimseg_hip.so")
+
+_CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argtype, argname), ...])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(const char\*|int)\s+(simseg_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    alist.append((ctypes.c_void_p, a.split("*")[-1].strip()))
+                else:
+                    ty, nm = a.rsplit(" ", 1)
+                    alist.append((_CT[ty], nm))
+        out[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, alist)
+    return out
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m simseg_amd.build` (hipcc, gfx950). "
+                "simseg_amd has no CPU or eager-PyTorch fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in parse_header().items():
+            fn = getattr(lib, name)       # AttributeError here == header/library mismatch
+            fn.restype = ret
+            fn.argtypes = [a for a, _ in args]
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {lib.simseg_last_error().decode()}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("simseg_amd ops run on MI355X only (tensor is on %s); there is no CPU fallback" % t.device)

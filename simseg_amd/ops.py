@@ -1,0 +1,159 @@
+"""Tensor-level wrappers over the C ABI (include/simseg_hip.h).  PyTorch supplies device memory and the stream;
+all arithmetic runs in libsimseg_hip.so.  No autograd here (see autograd.py) and no CPU fallback."""
+import torch
+
+from .lib import call, ptr, require_gpu, stream
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"simseg_amd supports fp32 and bf16 tensors, got {t.dtype}")
+
+
+def _c(t):
+    if t is not None and not t.is_contiguous():
+        raise ValueError("simseg_amd ops need contiguous tensors")
+    return t
+
+
+def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, rowscale=None,
+         residual=None, act=0, aux=None, aux_out=None, row_group=0, res_mod=False, accumulate=False, splitk=1,
+         drop_seed=0, drop_p=0.0, out_rows=None):
+    """C = epilogue(alpha * op(a) @ op(b)); a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b)."""
+    require_gpu(a, b)
+    _c(a); _c(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[1] if trans_b else b.shape[0]
+    kb = b.shape[0] if trans_b else b.shape[1]
+    if kb != K:
+        raise ValueError(f"gemm: inner dims differ ({K} vs {kb})")
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty(rows, N, device=a.device, dtype=out_dtype or a.dtype)
+    _c(out)
+    ldr = residual.shape[-1] if residual is not None else 0
+    call("simseg_gemm", ptr(a), ptr(b), ptr(out), M, N, K, a.shape[1], b.shape[1], out.shape[-1], dt(a), dt(out),
+         int(trans_a), int(trans_b), float(alpha), ptr(_c(bias)), ptr(_c(rowscale)), ptr(_c(residual)), ldr, int(act),
+         ptr(_c(aux)), ptr(_c(aux_out)), int(row_group), int(res_mod), int(accumulate), int(splitk), int(drop_seed),
+         float(drop_p), stream())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, want_bf16_copy=False, save_stats=False):
+    require_gpu(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    y16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16_copy else None
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    call("simseg_layernorm_fwd", ptr(_c(x)), ptr(gamma), ptr(beta), ptr(y), dt(y), ptr(y16), ptr(mean), ptr(rstd), rows, D,
+         float(eps), stream())
+    return y, y16, mean, rstd
+
+
+def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dres=None, want_f32=True, want_bf16=True):
+    require_gpu(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx32 = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_f32 else None
+    dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
+         ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), rows, D, stream())
+    return dx32, dx16
+
+
+def colsum_accum(x2d, out):
+    require_gpu(x2d)
+    call("simseg_colsum_accum", ptr(_c(x2d)), dt(x2d), ptr(out), x2d.shape[0], x2d.shape[1], x2d.shape[1], stream())
+    return out
+
+
+def vit_im2col(image, out_dtype):
+    require_gpu(image)
+    B, C, H, W = image.shape
+    if C != 3 or image.dtype != torch.float32:
+        raise ValueError("vit_im2col expects fp32 [B,3,H,W]")
+    cols = torch.empty(B * (H // 16) * (W // 16), 768, device=image.device, dtype=out_dtype)
+    call("simseg_vit_im2col", ptr(_c(image)), ptr(cols), dt(cols), B, H, W, stream())
+    return cols
+
+
+def vit_cls_rows(cls, pos, x):
+    B, T, D = x.shape
+    call("simseg_vit_cls_rows", ptr(cls), ptr(pos), ptr(x), B, T, D, stream())
+
+
+def vit_cls_grad(dx, dcls):
+    B, T, D = dx.shape
+    call("simseg_vit_cls_grad", ptr(_c(dx)), ptr(dcls), B, T, D, stream())
+
+
+def bert_embed_fwd(ids, word, pos, type_emb):
+    require_gpu(ids, word)
+    B, L = ids.shape
+    D = word.shape[1]
+    out = torch.empty(B, L, D, device=word.device, dtype=torch.float32)
+    call("simseg_bert_embed_fwd", ptr(_c(ids)), ptr(word), ptr(pos), ptr(type_emb), ptr(out), B, L, D, word.shape[0], stream())
+    return out
+
+
+def bert_embed_bwd(ids, mask, dsum, dword):
+    B, L = ids.shape
+    call("simseg_bert_embed_bwd", ptr(_c(ids)), ptr(_c(mask)), ptr(_c(dsum)), ptr(dword), B, L, dsum.shape[-1], dword.shape[0], stream())
+
+
+def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8):
+    require_gpu(tok)
+    B, N, P = tok.shape
+    emb = torch.empty(B, P, device=tok.device, dtype=torch.float32)
+    idx = torch.empty(B, k, P, device=tok.device, dtype=torch.int32)
+    norm = torch.empty(B, device=tok.device, dtype=torch.float32)
+    call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), B, N, P, int(k), float(eps), stream())
+    return emb, idx, norm
+
+
+def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8):
+    B, k, P = idx.shape
+    dtok = torch.empty(B, N, P, device=emb.device, dtype=dtype)
+    call("simseg_topk_pool_l2norm_bwd", ptr(_c(demb)), ptr(emb), ptr(norm), ptr(idx), ptr(dtok), dt(dtok), B, N, P, int(k), float(eps), stream())
+    return dtok
+
+
+def row_rnorm(x2d, eps=1e-12):
+    require_gpu(x2d)
+    rn = torch.empty(x2d.shape[0], device=x2d.device, dtype=torch.float32)
+    call("simseg_row_rnorm", ptr(_c(x2d)), dt(x2d), ptr(rn), x2d.shape[0], x2d.shape[1], float(eps), stream())
+    return rn
+
+
+def cast(x, dtype, out=None):
+    require_gpu(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    call("simseg_cast", ptr(_c(x)), ptr(out), x.numel(), int(dtype == torch.bfloat16), stream())
+    return out
+
+
+def transpose_f32(x2d):
+    require_gpu(x2d)
+    R, C = x2d.shape
+    out = torch.empty(C, R, device=x2d.device, dtype=torch.float32)
+    call("simseg_transpose_f32", ptr(_c(x2d)), ptr(out), R, C, stream())
+    return out
+
+
+def dropout_apply_(g, seed, p):
+    call("simseg_dropout_apply", ptr(_c(g)), dt(g), g.numel(), int(seed), float(p), stream())
+    return g
+
+
+def tr16_probe():
+    out = torch.empty(256, device="cuda", dtype=torch.int32)
+    call("simseg_debug_tr16_probe", ptr(out), stream())
+    return out.cpu().view(64, 4)

@@ -1,0 +1,219 @@
+"""Kernel-level parity on MI355X: every C-ABI entry point against a plain torch fp32 restatement of the same op
+on the same seeded inputs.  fp32 kernels: tolerance 1e-4 relative to the output scale (well inside the north-star
+1e-3); bf16-operand kernels: compared with torch fp32 on the SAME bf16-rounded inputs, tolerance 2e-2 of scale
+(bf16 output rounding) -- both written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simseg_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _close(got, want, tol, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def test_tr16_probe_layout(ops):
+    """ds_read_b64_tr_b16 with lane l addressing bytes [8l, 8l+8): every 16-lane group holds a [4][16] block and
+    lane a of the group receives column a (4 consecutive rows)."""
+    m = ops.tr16_probe().numpy()
+    want = np.zeros((64, 4), dtype=np.int32)
+    for l in range(64):
+        for j in range(4):
+            want[l, j] = (l >> 4) * 64 + j * 16 + (l & 15)
+    assert np.array_equal(m, want), f"unexpected tr16 layout:\n{m[:16]}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (788, 1152, 384), (325, 21, 512), (4, 512, 128), (1000, 264, 40)])
+def test_gemm_f32_nt(ops, M, N, K):
+    a, b = _rand(M, K, seed=1), _rand(N, K, seed=2)
+    _close(ops.gemm(a, b), a @ b.T, 1e-5, f"f32 NT {M}x{N}x{K}")
+
+
+def test_gemm_f32_epilogues(ops):
+    M, N, K = 300, 200, 64
+    a, b = _rand(M, K, seed=1), _rand(N, K, seed=2)
+    bias, rs, res = _rand(N, seed=3), _rand(M, seed=4).abs() + 0.5, _rand(M, N, seed=5)
+    ref = (a @ b.T) * 0.37 * rs[:, None] + bias
+    _close(ops.gemm(a, b, alpha=0.37, bias=bias, rowscale=rs), ref, 1e-5, "alpha/rowscale/bias")
+    pre = torch.empty(M, N, device="cuda")
+    _close(ops.gemm(a, b, bias=bias, act=1, aux_out=pre, residual=res), F.gelu(a @ b.T + bias) + res, 1e-5, "gelu+res")
+    _close(pre, a @ b.T + bias, 1e-5, "saved pre-activation")
+    # ViT token-row remap: rows of G patches land behind a [cls] row, residual = pos_embed[1 + r % G]
+    G, Bn = 25, 12
+    pos = _rand(G + 1, N, seed=6)
+    out = torch.zeros(Bn * (G + 1), N, device="cuda")
+    ops.gemm(a, b, bias=bias, residual=pos, row_group=G, res_mod=True, out=out)
+    ref = torch.zeros(Bn, G + 1, N, device="cuda")
+    ref[:, 1:] = (a @ b.T + bias).view(Bn, G, N) + pos[1:]
+    _close(out.view(Bn, G + 1, N), ref, 1e-5, "row_group")
+    acc = _rand(M, N, seed=7)
+    want = acc + a @ b.T
+    _close(ops.gemm(a, b, out=acc, accumulate=True), want, 1e-5, "accumulate")
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 256, 200), (768, 776, 1000), (72, 40, 24)])
+def test_gemm_bf16_layouts(ops, ta, tb, M, N, K):
+    if not ta:
+        K = (K + 7) // 8 * 8
+    a = _rand(*((K, M) if ta else (M, K)), seed=1, dtype=torch.bfloat16)
+    b = _rand(*((K, N) if tb else (N, K)), seed=2, dtype=torch.bfloat16)
+    A = a.float().T if ta else a.float()
+    Bm = b.float() if tb else b.float().T
+    ref = A @ Bm
+    _close(ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32), ref, 1e-5, f"bf16 ta={ta} tb={tb} f32 out")
+    _close(ops.gemm(a, b, trans_a=ta, trans_b=tb), ref, 1e-2, f"bf16 ta={ta} tb={tb} bf16 out")
+
+
+def test_gemm_bf16_splitk_and_dgelu(ops):
+    K, M, N = 5000, 256, 384          # wgrad shape: contraction over rows
+    dy, x = _rand(K, M, seed=1, dtype=torch.bfloat16), _rand(K, N, seed=2, dtype=torch.bfloat16)
+    acc = torch.zeros(M, N, device="cuda")
+    ops.gemm(dy, x, trans_a=True, trans_b=True, out=acc, accumulate=True, splitk=16)
+    _close(acc, dy.float().T @ x.float(), 2e-5, "split-K wgrad")
+    # dgrad with the GELU' epilogue
+    a, w = _rand(300, 256, seed=3, dtype=torch.bfloat16), _rand(256, 512, seed=4, dtype=torch.bfloat16)
+    pre = _rand(300, 512, seed=5, dtype=torch.bfloat16)
+    x32 = pre.float().requires_grad_(True)
+    F.gelu(x32).backward(torch.ones_like(x32))
+    # aux shares the output dtype (bf16 activations on the training path)
+    _close(ops.gemm(a, w, trans_b=True, act=2, aux=pre), (a.float() @ w.float()) * x32.grad, 1e-2, "dgelu")
+
+
+def test_gemm_dropout_epilogue(ops):
+    a, b = _rand(512, 64, seed=1), _rand(256, 64, seed=2)
+    y0 = ops.gemm(a, b)
+    y = ops.gemm(a, b, drop_seed=1234, drop_p=0.1)
+    kept = y != 0
+    frac = 1 - kept.float().mean().item()
+    assert abs(frac - 0.1) < 0.01, frac
+    _close(y[kept], y0[kept] / 0.9, 1e-5, "kept values scaled")
+    g = torch.ones_like(y0)
+    ops.dropout_apply_(g, 1234, 0.1)
+    assert torch.equal(g != 0, kept)          # backward regenerates the same mask
+    assert not torch.equal(ops.gemm(a, b, drop_seed=99, drop_p=0.1) != 0, kept)
+
+
+@pytest.mark.parametrize("D", [128, 384, 768, 1024])
+def test_layernorm_fwd_bwd(ops, D):
+    rows = 333
+    x = _rand(rows, D, seed=1, scale=3.0) + 0.5
+    g, b = _rand(D, seed=2) * 0.2 + 1.0, _rand(D, seed=3) * 0.1
+    for eps in (1e-6, 1e-12):
+        y, y16, mean, rstd = ops.layernorm_fwd(x, g, b, eps, want_bf16_copy=True, save_stats=True)
+        ref = F.layer_norm(x, (D,), g, b, eps)
+        _close(y, ref, 1e-5, "ln fwd")
+        _close(y16, ref, 1e-2, "ln fwd bf16 copy")
+    yb, *_ = ops.layernorm_fwd(x, g, b, 1e-6, out_dtype=torch.bfloat16)
+    _close(yb, ref, 1e-2, "ln fwd bf16 out")
+    # backward:  dy = dy16 + dy32,  dx = LN'(dy) + dres
+    dy32, dy16, dres = _rand(rows, D, seed=4), _rand(rows, D, seed=5, dtype=torch.bfloat16), _rand(rows, D, seed=6)
+    xr = x.clone().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, 1e-12).backward(dy32 + dy16.float())
+    dgam = torch.zeros(D, device="cuda"); dbet = torch.zeros(D, device="cuda")
+    dx32, dx16 = ops.layernorm_bwd(x, mean, rstd, g, dgam, dbet, dy16=dy16, dy32=dy32, dres=dres)
+    _close(dx32, xr.grad + dres, 2e-5, "ln bwd dx")
+    _close(dx16, xr.grad + dres, 1e-2, "ln bwd dx bf16")
+    _close(dgam, gr.grad, 1e-4, "ln bwd dgamma")
+    _close(dbet, br.grad, 1e-4, "ln bwd dbeta")
+
+
+def test_colsum_transpose_cast(ops):
+    x = _rand(1001, 776, seed=1)
+    out = torch.ones(776, device="cuda")
+    ops.colsum_accum(x, out)
+    _close(out, 1 + x.sum(0), 1e-5, "colsum f32")
+    xb = x.bfloat16()
+    out = torch.zeros(776, device="cuda")
+    ops.colsum_accum(xb, out)
+    _close(out, xb.float().sum(0), 1e-5, "colsum bf16")
+    assert torch.equal(ops.transpose_f32(x), x.T.contiguous())
+    assert torch.equal(ops.cast(x, torch.bfloat16), x.bfloat16())
+    assert torch.equal(ops.cast(xb, torch.float32), xb.float())
+
+
+def test_vit_patch_embed(ops):
+    """im2col + GEMM(row_group) + cls rows == Conv2d patch embed, cls concat, +pos (vit_builder.py:14-17)."""
+    B, D, S = 3, 128, 96
+    N = (S // 16) ** 2
+    img = _rand(B, 3, S, S, seed=1)
+    w, bias = _rand(D, 3, 16, 16, seed=2, scale=0.05), _rand(D, seed=3)
+    cls, pos = _rand(1, 1, D, seed=4), _rand(1, 1 + N, D, seed=5)
+    ref = F.conv2d(img, w, bias, stride=16).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(B, -1, -1), ref], 1) + pos
+    x = torch.empty(B, 1 + N, D, device="cuda")
+    cols = ops.vit_im2col(img, torch.float32)
+    ops.gemm(cols, w.view(D, 768), bias=bias, residual=pos.view(1 + N, D), row_group=N, res_mod=True, out=x.view(-1, D))
+    ops.vit_cls_rows(cls.view(-1), pos.view(-1), x)
+    _close(x, ref, 1e-5, "patch embed")
+
+
+def test_bert_embed(ops):
+    B, L, D, V = 5, 25, 128, 1000
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, L), generator=g).cuda()
+    mask = (torch.rand(B, L, generator=g) < 0.7).long().cuda()
+    word, pos, typ = _rand(V, D, seed=1), _rand(128, D, seed=2), _rand(2, D, seed=3)
+    out = ops.bert_embed_fwd(ids, word, pos, typ[0].contiguous())
+    ref = word[ids] + typ[0] + pos[:L][None]
+    _close(out, ref, 1e-6, "bert embed")
+    dsum = _rand(B, L, D, seed=4)
+    dword = torch.zeros(V, D, device="cuda")
+    ops.bert_embed_bwd(ids, mask, dsum, dword)
+    refw = torch.zeros(V, D, device="cuda").index_add_(0, ids.view(-1), (dsum * mask[..., None]).view(-1, D))
+    _close(dword, refw, 1e-5, "bert embed bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_topk_pool_l2norm(ops, golden, dtype):
+    from conftest import tt
+    g = golden("heads")
+    tok = tt(g["tok"]).cuda().to(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    emb, idx, norm = ops.topk_pool_l2norm_fwd(tok, 5)
+    x = tok.float().requires_grad_(True)
+    pooled = x.topk(5, dim=1)[0].mean(1)
+    ref = pooled / (pooled.pow(2).sum(-1, keepdim=True).sqrt() + 1e-8)
+    _close(emb, ref, 1e-5, "loda image pool")
+    if dtype == torch.float32:
+        _close(emb, tt(g["emb"]), 1e-5, "loda image pool vs reference fixture")
+    gy = tt(g["gy"]).cuda()
+    ref.backward(gy)
+    dtok = ops.topk_pool_l2norm_bwd(gy, emb, norm, idx, tok.shape[1], dtype)
+    _close(dtok, x.grad, tol, "loda pool bwd")
+    # masked text pooling k=1 (pipelines/clip.py:111-120)
+    t, mask = tt(g["t"]).cuda().to(dtype), tt(g["mask"]).cuda()
+    temb, tidx, tnorm = ops.topk_pool_l2norm_fwd(t, 1, mask)
+    if dtype == torch.float32:
+        _close(temb, tt(g["temb"]), 1e-5, "masked text pool vs reference fixture")
+        dt_ = ops.topk_pool_l2norm_bwd(tt(g["gt"]).cuda(), temb, tnorm, tidx, t.shape[1], dtype)
+        _close(dt_, tt(g["gt_in"]), 1e-5, "masked text pool bwd vs reference fixture")
+    _close(ops.topk_pool_l2norm_fwd(t, 2, tt(g["mask2"]).cuda())[0],
+           (lambda p: p / (p.norm(dim=-1, keepdim=True) + 1e-8))(
+               torch.where(tt(g["mask2"]).cuda()[..., None] == 0, torch.full_like(t.float(), -10000.), t.float()).topk(2, dim=1)[0].mean(1)),
+           1e-5, "masked pool k=2")
+
+
+def test_row_rnorm(ops):
+    x = _rand(777, 512, seed=1, scale=4.0)
+    _close(ops.row_rnorm(x), 1.0 / x.norm(dim=-1).clamp_min(1e-12), 1e-5, "rnorm")
+    _close(ops.row_rnorm(x.bfloat16()), 1.0 / x.bfloat16().float().norm(dim=-1).clamp_min(1e-12), 1e-5, "rnorm bf16")
