@@ -69,8 +69,43 @@ int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask,
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, void* stream);
 
+/* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
+ * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]
+ * (log2 domain, optional) is saved for the backward.  dtype 0 = exact fp32 MFMA, 1 = bf16 MFMA.  drop_p > 0 applies
+ * HF attention_probs dropout (bf16 only).  Replaces timm Attention.forward (q@k^T*scale, softmax, @v) and HF
+ * BertSelfAttention.forward as reached through vit_builder.py:18 / huggingface_builder.py:16-17. */
+int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B, int64_t T,
+                         int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream);
+/* bf16 backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse; delta[B,H,T] is caller-provided fp32 scratch. */
+int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
+                         float* delta, void* dqkv, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
+                         float drop_p, void* stream);
+
 /* rnorm[r] = 1 / max(||x_r||_2, eps): the F.normalize of tools/seg_evaluation.py:112 as a GEMM row scale. */
 int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t rows, int64_t D, float eps, void* stream);
+
+/* InfoNCE rows over sims[N1,N2] = feat1 . feat2_global^T (fp32, from simseg_gemm): z = s / clamp(T,1e-3,0.5),
+ * per-row cross-entropy against target column target0 + i with optional label smoothing and ignore weights, top-1
+ * hit, and (write_grad) dLoss/ds written IN PLACE over sims.  out3 = {loss, top-1 acc, dLoss/dT}.
+ * simseg/models/criteria/losses/mml_loss.py:56,73-77,89-95 (+ :350-376 LabelSmoothingCrossEntropy,
+ * simseg/utils/misc.py:462-478 calc_topk_accuracy). */
+int simseg_nce_rows(float* sims, const float* temperature, const float* ignore_mask, float* row_loss, float* row_correct,
+                    float* row_tdot, float* out3, int64_t N1, int64_t N2, int64_t target0, float smoothing, int write_grad,
+                    void* stream);
+/* y[r,:] = alpha * x[r,:] * (one_minus ? 1 - s[r] : s[r])  -- feat2_global * (1 - ignore_mask), mml_loss.py:70-71. */
+int simseg_scale_rows(const float* x, const float* s, float* y, int64_t rows, int64_t D, int one_minus, float alpha, void* stream);
+
+/* Retrieval: rank[i] = #{j : sim_ij > max_{j': gid match} sim_ij'}, has_match[i] = any gid match.  Equals the
+ * argsort/gather/first-match rank of simseg/tasks/clip/hooks/utils.py:36-42,64-66 on tie-free scores. */
+int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, const int64_t* right_gid, int32_t* has_match, int32_t* rank,
+                          int64_t M, int64_t N, int64_t ld, void* stream);
+/* counts4 = {#has_match, #rank<b0, #rank<b1, #rank<b2}  (hooks/utils.py:69-71). */
+int simseg_recall_counts(const int32_t* has_match, const int32_t* rank, int64_t M, int b0, int b1, int b2, int32_t* counts4,
+                         void* stream);
+
+/* torch.optim.AdamW (configs/clip/simseg.vit-b.yaml:31-36) over a flat fp32 segment; refreshes the bf16 compute copy. */
+int simseg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
 int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);

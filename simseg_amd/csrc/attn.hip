@@ -1,0 +1,581 @@
+// Fused softmax attention (K5 of SURVEY.md 2.2) for head_dim 64: timm Attention (no mask, scale 64^-0.5) and
+// HF BertSelfAttention (key-padding mask, optional attention-prob dropout).  Flash-style: the T x T score matrix is
+// never written to HBM; K/V tiles of 64 keys are staged in LDS, softmax runs online in registers.
+//
+// Input is the packed projection qkv[B,T,3,H,64] (timm's qkv Linear layout; BERT's query/key/value weights are
+// stored adjacently so the same single GEMM produces it).  Output ctx[B,T,H*64] is what the out-projection consumes.
+//
+// MFMA orientation ("swapped QK^T"): S^T = K.Q^T is computed with keys as MFMA rows and queries as MFMA columns, so a
+// lane owns ONE query column (lane%32) and 16 of every 32 keys: the row max / row sum are in-lane reductions plus a
+// single exchange with lane^32.  The PV product is taken as O^T = V^T.P^T so that the accumulator is again indexed
+// by query per lane (the online-softmax rescale is lane-local) and P feeds the MFMA B operand straight from the
+// score registers; V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (bf16) or plain b32
+// reads (fp32).  fp32 path = v_mfma_f32_32x32x2_f32 (exact), bf16 path = v_mfma_f32_32x32x16_bf16.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;            // keys per LDS tile
+constexpr float NEG = -1e30f;
+
+struct AttnParams {
+    const void* qkv; const long* mask; void* out; float* lse;
+    int B, T, H;
+    float scale_log2e;
+    unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
+    // backward
+    const void* dout; const float* delta; void* dqkv;
+};
+
+// online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
+__device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias, int h2, float scale_log2e, float& m,
+                                             float& lsum, float& alpha) {
+    float mx = NEG;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const float x = s[kb][r] * scale_log2e + kbias[key];
+            s[kb][r] = x;
+            mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    alpha = exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(s[kb][r] - mn);
+            s[kb][r] = p;
+            ps += p;
+        }
+    lsum = lsum * alpha + ps;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 forward
+// ------------------------------------------------------------------------------------------------
+constexpr int KP32 = 272, VP32 = 256;
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[KT * KP32 + KT * VP32 + KT * 4];
+    char* ldsK = lds;
+    char* ldsV = lds + KT * KP32;
+    float* kbias = reinterpret_cast<float*>(lds + KT * KP32 + KT * VP32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64;
+    const float* base = static_cast<const float*>(p.qkv) + (long)b * T * RS + h * 64;
+    const int q = blockIdx.x * 128 + wave * 32 + ql;
+
+    float qr[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < T) v = *reinterpret_cast<const float4*>(base + (long)q * RS + 8 * c + 4 * h2);
+        qr[c][0] = v.x; qr[c][1] = v.y; qr[c][2] = v.z; qr[c][3] = v.w;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = NEG, lsum = 0.f;
+
+    for (int kv0 = 0; kv0 < T; kv0 += KT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // 64 keys x 16 chunks of 16 B, for K and V
+            const int idx = tid + 256 * i;
+            const int key = idx >> 4, c = idx & 15;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (kv0 + key < T) {
+                const float* rp = base + (long)(kv0 + key) * RS + c * 4;
+                kv = *reinterpret_cast<const float4*>(rp + p.H * 64);
+                vv = *reinterpret_cast<const float4*>(rp + 2 * p.H * 64);
+            }
+            *reinterpret_cast<float4*>(ldsK + key * KP32 + c * 16) = kv;
+            *reinterpret_cast<float4*>(ldsV + key * VP32 + c * 16) = vv;
+        }
+        if (tid < KT) {
+            const int key = kv0 + tid;
+            kbias[tid] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        }
+        __syncthreads();
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(ldsK + (kb * 32 + ql) * KP32 + (8 * c + 4 * h2) * 4);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qr[c][0], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qr[c][1], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qr[c][2], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qr[c][3], s[kb], 0, 0, 0);
+            }
+        }
+        float alpha;
+        softmax_tile(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const float v = *reinterpret_cast<const float*>(ldsV + key * VP32 + (db * 32 + ql) * 4);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[kb][r], o[db], 0, 0, 0);
+                }
+            }
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (q < T) {
+        float* orow = static_cast<float*>(p.out) + ((long)b * T + q) * p.H * 64 + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * r4] * inv, o[db][4 * r4 + 1] * inv, o[db][4 * r4 + 2] * inv, o[db][4 * r4 + 3] * inv);
+            }
+        if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 forward
+// ------------------------------------------------------------------------------------------------
+constexpr int KP16 = 144, VP16 = 192;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, int row_step_bytes) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + row_step_bytes));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) {
+    union { u32x4 v; bf16x8 h; } u;
+    u.v = *reinterpret_cast<const u32x4*>(p);
+    return u.h;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * VP16 + KT * 4];
+    char* ldsK = lds;
+    char* ldsV = lds + KT * KP16;
+    float* kbias = reinterpret_cast<float*>(lds + KT * KP16 + KT * VP16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const int q = blockIdx.x * 128 + wave * 32 + ql;
+
+    bf16x8 qr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        union { u32x4 v; bf16x8 hh; } u;
+        u.v = (u32x4){0u, 0u, 0u, 0u};
+        if (q < T) u.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
+        qr[kk] = u.hh;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = NEG, lsum = 0.f;
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+
+    for (int kv0 = 0; kv0 < T; kv0 += KT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {      // 64 keys x 8 chunks of 16 B, for K and V
+            const int idx = tid + 256 * i;
+            const int key = idx >> 3, c = idx & 7;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
+            if (kv0 + key < T) {
+                const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
+                kv = *reinterpret_cast<const u32x4*>(rp + p.H * 64);
+                vv = *reinterpret_cast<const u32x4*>(rp + 2 * p.H * 64);
+            }
+            *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = kv;
+            *reinterpret_cast<u32x4*>(ldsV + key * VP16 + c * 16) = vv;
+        }
+        if (tid < KT) {
+            const int key = kv0 + tid;
+            kbias[tid] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        }
+        __syncthreads();
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 a = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qr[kk], s[kb], 0, 0, 0);
+            }
+        }
+        float alpha;
+        softmax_tile(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        if (p.drop_thresh) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + key;
+                    s[kb][r] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
+                }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
+                const int k0 = kb * 32 + 16 * s2 + 4 * h2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* vp = ldsV + (k0 + (a16 >> 2)) * VP16 + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
+                    const bf16x8 vf = tr_frag(vp, 8 * VP16);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                }
+            }
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (q < T) {
+        bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * T + q) * p.H * 64 + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                bf16x4 v = {(bf16_t)(o[db][4 * r4] * inv), (bf16_t)(o[db][4 * r4 + 1] * inv), (bf16_t)(o[db][4 * r4 + 2] * inv), (bf16_t)(o[db][4 * r4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(orow + d) = v;
+            }
+        if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 backward.  delta[b,h,q] = sum_d dO.O ;  P = exp2(S*c + bias - lse) ;  dS = P o (dP - delta) * scale
+//   kernel A (per 128-key tile): dK = dS^T.Q, dV = P_d^T.dO      (queries streamed through LDS, 32 at a time)
+//   kernel B (per 128-query tile): dQ = dS.K                     (keys streamed through LDS, 64 at a time)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int T, int H) {
+    // one 8-lane group per (b, t, h): 64 d = 8 lanes x 8 elements
+    const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    if (gid >= (long)B * T * H) return;
+    const long off = gid * 64 + sub * 8;
+    const bf16x8 a = ld_bf16x8(o + off), g = ld_bf16x8(dout + off);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)g[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (sub == 0) {
+        const int h = (int)(gid % H);
+        const long bt = gid / H;
+        const int t = (int)(bt % T);
+        const int b = (int)(bt / T);
+        delta[((long)b * H + h) * T + t] = s;
+    }
+}
+
+constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
+constexpr int QP = 144;  // pitch of the Q / dO tiles (read both k-contiguous and transposed)
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * QT * QP + 2 * QT * 4];
+    char* ldsQ = lds;
+    char* ldsG = lds + QT * QP;                         // dO tile
+    float* lseq = reinterpret_cast<float*>(lds + 2 * QT * QP);
+    float* delq = lseq + QT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, kl = lane & 31;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const int key = blockIdx.x * 128 + wave * 32 + kl;
+    const bool kvalid = key < T;
+    const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+
+    bf16x8 kr[4], vr[4];     // this lane's K and V row chunks: B operands of S = Q.K^T and dP = dO.V^T
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        union { u32x4 v; bf16x8 hh; } uk, uv;
+        uk.v = (u32x4){0u, 0u, 0u, 0u}; uv.v = uk.v;
+        if (kvalid) {
+            uk.v = *reinterpret_cast<const u32x4*>(base + (long)key * RS + p.H * 64 + (2 * kk + h2) * 8);
+            uv.v = *reinterpret_cast<const u32x4*>(base + (long)key * RS + 2 * p.H * 64 + (2 * kk + h2) * 8);
+        }
+        kr[kk] = uk.hh; vr[kk] = uv.hh;
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const float scale = p.scale_log2e * 0.6931471805599453f;
+
+    for (int q0 = 0; q0 < T; q0 += QT) {
+        __syncthreads();
+        {   // 32 queries x 8 chunks = 256 chunks each for Q and dO
+            const int qq = tid >> 3, c = tid & 7;
+            u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
+            if (q0 + qq < T) {
+                qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c * 8);
+                gv = *reinterpret_cast<const u32x4*>(gbase + (long)(q0 + qq) * OS + c * 8);
+            }
+            *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = qv;
+            *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = gv;
+            if (tid < QT) {
+                const bool v = q0 + tid < T;
+                lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + q0 + tid] : 1e30f;   // -> P = 0 for padded queries
+                delq[tid] = v ? p.delta[((long)b * p.H + h) * T + q0 + tid] : 0.f;
+            }
+        }
+        __syncthreads();
+        // S[q][key], dP[q][key]: MFMA rows = queries (A from LDS), columns = keys (B = this lane's K / V row)
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 aq = ld_bf16x8(ldsQ + kl * QP + (2 * kk + h2) * 16);
+            const bf16x8 ag = ld_bf16x8(ldsG + kl * QP + (2 * kk + h2) * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kr[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vr[kk], dp, 0, 0, 0);
+        }
+        // lane: key column kl, rows q = (r%4) + 8*(r/4) + 4*h2
+        float pd[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const float pr = exp2f(s[r] * p.scale_log2e + kb_ - lseq[qq]);
+            float keep = 1.f;
+            if (p.drop_thresh) {
+                const unsigned long long idx = ((unsigned long long)blockIdx.y * T + (q0 + qq)) * T + key;
+                keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
+            }
+            pd[r] = pr * keep;                                   // dropped probabilities feed dV
+            ds[r] = pr * (dp[r] * keep - delq[qq]) * scale;     // dS feeds dK
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf, df;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)pd[8 * s2 + e]; df[e] = (bf16_t)ds[8 * s2 + e]; }
+            const int r0 = 16 * s2 + 4 * h2;      // query rows of k-slots e<4; e>=4 are 8 rows further
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int off = (r0 + (a16 >> 2)) * QP + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
+                const bf16x8 gf = tr_frag(ldsG + off, 8 * QP);    // dO^T fragment: [q-slots][d]
+                const bf16x8 qf = tr_frag(ldsQ + off, 8 * QP);    // Q^T fragment
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qf, dk[db], 0, 0, 0);
+            }
+        }
+    }
+    // dk/dv accumulators: rows = keys (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32
+    bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (krow < T) {
+                dbase[(long)krow * RS + p.H * 64 + db * 32 + kl] = (bf16_t)dk[db][r];
+                dbase[(long)krow * RS + 2 * p.H * 64 + db * 32 + kl] = (bf16_t)dv[db][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * KP16 + KT * 4];
+    char* ldsK = lds;
+    char* ldsV = lds + KT * KP16;
+    float* kbias = reinterpret_cast<float*>(lds + 2 * KT * KP16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    const bool qvalid = q < T;
+
+    bf16x8 qr[4], gr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        union { u32x4 v; bf16x8 hh; } uq, ug;
+        uq.v = (u32x4){0u, 0u, 0u, 0u}; ug.v = uq.v;
+        if (qvalid) {
+            uq.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
+            ug.v = *reinterpret_cast<const u32x4*>(gbase + (long)q * OS + (2 * kk + h2) * 8);
+        }
+        qr[kk] = uq.hh; gr[kk] = ug.hh;
+    }
+    const float lse = qvalid ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;
+    const float del = qvalid ? p.delta[((long)b * p.H + h) * T + q] : 0.f;
+    const float scale = p.scale_log2e * 0.6931471805599453f;
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+
+    for (int kv0 = 0; kv0 < T; kv0 += KT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx >> 3, c = idx & 7;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
+            if (kv0 + key < T) {
+                const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
+                kv = *reinterpret_cast<const u32x4*>(rp + p.H * 64);
+                vv = *reinterpret_cast<const u32x4*>(rp + 2 * p.H * 64);
+            }
+            *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = kv;
+            *reinterpret_cast<u32x4*>(ldsV + key * KP16 + c * 16) = vv;
+        }
+        if (tid < KT) {
+            const int key = kv0 + tid;
+            kbias[tid] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            // S^T[key][q], dP^T[key][q]: rows = keys (A from LDS), columns = queries (B = this lane's Q / dO row)
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 ak = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
+                const bf16x8 av = ld_bf16x8(ldsV + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gr[kk], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                const float pr = exp2f(s[r] * p.scale_log2e + kbias[kk_] - lse);
+                float keep = 1.f;
+                if (p.drop_thresh) {
+                    const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + (kv0 + kk_);
+                    keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                }
+                ds[r] = pr * (dp[r] * keep - del) * scale;
+            }
+            // dQ[q][d] += dS[q][keys] . K[keys][d] : A = dS (this lane's query row, key k-slots), B = K^T via tr reads
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 df;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) df[e] = (bf16_t)ds[8 * s2 + e];
+                const int k0 = kb * 32 + 16 * s2 + 4 * h2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* kp = ldsK + (k0 + (a16 >> 2)) * KP16 + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
+                    const bf16x8 kf = tr_frag(kp, 8 * KP16);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, kf, dq[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // dq accumulators: rows = queries (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32
+    bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (qrow < T) dbase[(long)qrow * RS + db * 32 + ql] = (bf16_t)dq[db][r];
+        }
+}
+
+int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
+                uint64_t seed, float drop_p) {
+    SS_CHECK(qkv, "attention: null qkv");
+    SS_CHECK(B > 0 && T > 0 && H > 0 && B * H < 65536 * 16, "attention: bad shape");
+    SS_CHECK(((uintptr_t)qkv % 16) == 0, "attention: qkv must be 16-byte aligned");
+    SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention: dropout p out of range");
+    memset(&p, 0, sizeof(p));
+    p.qkv = qkv; p.mask = (const long*)mask; p.B = (int)B; p.T = (int)T; p.H = (int)H;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    p.drop_seed = seed;
+    p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
+    p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    return 0;
+}
+
+}  // namespace
+
+// ctx[B,T,H*64] = softmax(q k^T * scale + keymask) v  from packed qkv[B,T,3,H,64]; lse[B,H,T] (log2 domain) optional.
+extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B,
+                                    int64_t T, int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream) {
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out, "attention_fwd: null out");
+    SS_CHECK(dtype == 1 || drop_p == 0.f, "attention_fwd: dropout is a training (bf16) feature");
+    p.out = out; p.lse = lse;
+    dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H));
+    if (dtype == 0)
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    SS_LAUNCH_CHECK("attention_fwd");
+    return 0;
+}
+
+// bf16 backward: dqkv[B,T,3,H,64] from qkv, ctx (forward output), dctx, lse; delta[B,H,T] is caller-provided scratch.
+extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
+                                    float* delta, void* dqkv, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
+                                    float drop_p, void* stream) {
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out && dout && lse && delta && dqkv, "attention_bwd: null pointer");
+    p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta; p.dqkv = dqkv;
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = B * T * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
+                       (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
+    dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, p);
+    SS_LAUNCH_CHECK("attention_bwd");
+    return 0;
+}

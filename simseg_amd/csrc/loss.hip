@@ -1,0 +1,244 @@
+// Row kernels behind the similarity matrices: InfoNCE cross-entropy rows (K13), retrieval first-match ranks (K16),
+// and the fused AdamW step over the flat parameter buffer.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+    return s;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = -INFINITY;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s = fmaxf(s, sh[i]);
+    return s;
+}
+
+// One block per local row i of sims[N1,N2] = feat1 . feat2_global^T  (mml_loss.py:73-77, 89-95, 350-376).
+//   z = s / clamp(T, 1e-3, 0.5);  loss_i = (1-eps) * nll_i + eps * mean_j(-logp_ij);  weight w_i = 1 - ignore_i
+//   total loss = (1/N1) sum_i w_i loss_i.   Writes (in place) dS_ij = dLoss/ds_ij, and per-row partials.
+__global__ __launch_bounds__(256) void nce_rows_kernel(float* __restrict__ sims, const float* __restrict__ temperature,
+                                                       const float* __restrict__ ignore, float* __restrict__ row_loss,
+                                                       float* __restrict__ row_correct, float* __restrict__ row_tdot,
+                                                       int N1, int N2, int target0, float smoothing, int write_grad) {
+    __shared__ float sh[8];
+    __shared__ int shi[8];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float* row = sims + (long)i * N2;
+    const float temp = fminf(fmaxf(temperature[0], 0.001f), 0.5f);
+    const float inv_t = 1.0f / temp;
+    const int tgt = target0 + i;
+    float mx = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int j = tid; j < N2; j += 256) {
+        const float z = row[j] * inv_t;
+        if (z > mx) { mx = z; arg = j; }
+    }
+    const float bmx = block_reduce_max(mx, sh);
+    // first index attaining the maximum
+    int cand = (mx == bmx) ? arg : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) shi[tid >> 6] = cand;
+    __syncthreads();
+    int best = 0x7fffffff;
+    for (int w = 0; w < 4; ++w) best = min(best, shi[w]);
+    float se = 0.f, sz = 0.f;
+    for (int j = tid; j < N2; j += 256) {
+        const float z = row[j] * inv_t;
+        se += __expf(z - bmx);
+        sz += z;
+    }
+    se = block_reduce_sum(se, sh);
+    sz = block_reduce_sum(sz, sh);
+    const float lse = bmx + __logf(se);
+    const float zt = row[tgt] * inv_t;
+    const float nll = lse - zt;
+    const float smooth = lse - sz / N2;                 // -mean_j logp_ij
+    const float w = ignore ? 1.0f - ignore[i] : 1.0f;
+    const float loss = (1.0f - smoothing) * nll + smoothing * smooth;
+    __syncthreads();
+    float tdot = 0.f;
+    if (write_grad) {
+        const float c = w / N1;
+        for (int j = tid; j < N2; j += 256) {
+            const float s = row[j];
+            const float pj = __expf(s * inv_t - lse);
+            float dz = pj - smoothing / N2;
+            if (j == tgt) dz -= (1.0f - smoothing);
+            dz *= c;
+            tdot += dz * s;
+            row[j] = dz * inv_t;
+        }
+        tdot = block_reduce_sum(tdot, sh);
+    }
+    if (tid == 0) {
+        row_loss[i] = loss * w;
+        row_correct[i] = (best == tgt) ? 1.f : 0.f;
+        row_tdot[i] = tdot;
+    }
+}
+
+// out[0] = loss = mean_i row_loss ; out[1] = top-1 acc over kept rows ; out[2] = dLoss/dTemperature
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ row_loss, const float* __restrict__ row_correct,
+                                                           const float* __restrict__ row_tdot, const float* __restrict__ ignore,
+                                                           const float* __restrict__ temperature, float* __restrict__ out, int N1) {
+    __shared__ float sh[8];
+    float l = 0.f, c = 0.f, k = 0.f, t = 0.f;
+    for (int i = threadIdx.x; i < N1; i += 256) {
+        const bool keep = !ignore || ignore[i] < 1.0f;
+        l += row_loss[i];
+        t += row_tdot[i];
+        if (keep) { c += row_correct[i]; k += 1.f; }
+    }
+    l = block_reduce_sum(l, sh); c = block_reduce_sum(c, sh); k = block_reduce_sum(k, sh); t = block_reduce_sum(t, sh);
+    if (threadIdx.x == 0) {
+        const float T = temperature[0];
+        const float temp = fminf(fmaxf(T, 0.001f), 0.5f);
+        out[0] = l / N1;
+        out[1] = c / k;
+        // z = s / temp  ->  dL/dtemp = -(1/temp) * sum_ij dz_ij * s_ij / temp ... with tdot = sum dz*s:  -tdot / temp^2
+        out[2] = (T >= 0.001f && T <= 0.5f) ? -t / (temp * temp) : 0.f;
+    }
+}
+
+// y[r,:] = x[r,:] * (one_minus ? 1 - s[r] : s[r]) * alpha
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, long rows,
+                                  int D, int one_minus, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * D; i += (long)gridDim.x * blockDim.x) {
+        const float f = s ? (one_minus ? 1.0f - s[i / D] : s[i / D]) : 1.0f;
+        y[i] = x[i] * f * alpha;
+    }
+}
+
+// Retrieval (hooks/utils.py:36-42, 64-66): for left row i, best = max_j{sim_ij : gid match}; rank = #{j : sim_ij > best}.
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ sim, const long* __restrict__ lgid,
+                                                             const long* __restrict__ rgid, int* __restrict__ has,
+                                                             int* __restrict__ rank, int N, long ld) {
+    __shared__ float sh[8];
+    const long i = blockIdx.x;
+    const float* row = sim + i * ld;
+    const long g = lgid[i];
+    float best = -INFINITY;
+    for (int j = threadIdx.x; j < N; j += 256)
+        if (rgid[j] == g) best = fmaxf(best, row[j]);
+    best = block_reduce_max(best, sh);
+    float cnt = 0.f;
+    for (int j = threadIdx.x; j < N; j += 256) cnt += (row[j] > best) ? 1.f : 0.f;
+    cnt = block_reduce_sum(cnt, sh);
+    if (threadIdx.x == 0) {
+        has[i] = best > -INFINITY ? 1 : 0;
+        rank[i] = (int)cnt;
+    }
+}
+
+// counts[0] = #rows with a match, counts[1..nb] = #rows with a match and rank < bound_b
+__global__ __launch_bounds__(256) void recall_count_kernel(const int* __restrict__ has, const int* __restrict__ rank, long M,
+                                                           int b0, int b1, int b2, int* __restrict__ counts) {
+    int c[4] = {0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long)gridDim.x * blockDim.x) {
+        if (has[i]) {
+            c[0]++;
+            c[1] += rank[i] < b0; c[2] += rank[i] < b1; c[3] += rank[i] < b2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int v = c[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + k, v);
+    }
+}
+
+// torch.optim.AdamW step on a flat fp32 segment, optionally refreshing the bf16 compute copy of the weights.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ p16, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                             float bc2_sqrt, float grad_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (p16) p16[i] = (bf16_t)pi;
+    }
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+
+extern "C" int simseg_nce_rows(float* sims, const float* temperature, const float* ignore_mask, float* row_loss, float* row_correct,
+                               float* row_tdot, float* out3, int64_t N1, int64_t N2, int64_t target0, float smoothing,
+                               int write_grad, void* stream) {
+    SS_CHECK(sims && temperature && row_loss && row_correct && row_tdot && out3, "nce_rows: null pointer");
+    SS_CHECK(N1 > 0 && N2 > 0 && target0 >= 0 && target0 + N1 <= N2, "nce_rows: targets [%lld, %lld) outside [0, %lld)",
+             (long long)target0, (long long)(target0 + N1), (long long)N2);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3((unsigned)N1), dim3(256), 0, STREAM, sims, temperature, ignore_mask, row_loss, row_correct,
+                       row_tdot, (int)N1, (int)N2, (int)target0, smoothing, write_grad);
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, STREAM, row_loss, row_correct, row_tdot, ignore_mask, temperature,
+                       out3, (int)N1);
+    SS_LAUNCH_CHECK("nce_rows");
+    return 0;
+}
+
+extern "C" int simseg_scale_rows(const float* x, const float* s, float* y, int64_t rows, int64_t D, int one_minus, float alpha,
+                                 void* stream) {
+    SS_CHECK(x && y, "scale_rows: null pointer");
+    if (rows * D <= 0) return 0;
+    long blocks = (rows * D + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, s, y, (long)rows, (int)D, one_minus, alpha);
+    SS_LAUNCH_CHECK("scale_rows");
+    return 0;
+}
+
+extern "C" int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, const int64_t* right_gid, int32_t* has_match,
+                                     int32_t* rank, int64_t M, int64_t N, int64_t ld, void* stream) {
+    SS_CHECK(sim && left_gid && right_gid && has_match && rank, "retrieval_rank: null pointer");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((unsigned)M), dim3(256), 0, STREAM, sim, (const long*)left_gid, (const long*)right_gid,
+                       has_match, rank, (int)N, (long)ld);
+    SS_LAUNCH_CHECK("retrieval_rank");
+    return 0;
+}
+
+extern "C" int simseg_recall_counts(const int32_t* has_match, const int32_t* rank, int64_t M, int b0, int b1, int b2,
+                                    int32_t* counts4, void* stream) {
+    SS_CHECK(has_match && rank && counts4, "recall_counts: null pointer");
+    hipMemsetAsync(counts4, 0, 4 * sizeof(int), STREAM);
+    long blocks = (M + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(recall_count_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, has_match, rank, (long)M, b0, b1, b2, counts4);
+    SS_LAUNCH_CHECK("recall_counts");
+    return 0;
+}
+
+extern "C" int simseg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    SS_CHECK(p && g && m && v, "adamw_step: null pointer");
+    SS_CHECK(step >= 1, "adamw_step: step counts from 1");
+    if (n <= 0) return 0;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    long blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, sqrtf(bc2), grad_scale);
+    SS_LAUNCH_CHECK("adamw_step");
+    return 0;
+}

@@ -125,6 +125,28 @@ def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8):
     return dtok
 
 
+def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0):
+    """qkv [B,T,3*H*64] packed (3,H,64) -> ctx [B,T,H*64]."""
+    require_gpu(qkv)
+    B, T, W = qkv.shape
+    if W != 3 * heads * 64:
+        raise ValueError("attention: qkv last dim must be 3*heads*64")
+    out = torch.empty(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
+    call("simseg_attention_fwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(out), ptr(lse), dt(qkv), B, T, heads, float(scale),
+         int(drop_seed), float(drop_p), stream())
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0):
+    B, T, W = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(delta), ptr(dqkv),
+         B, T, heads, float(scale), int(drop_seed), float(drop_p), stream())
+    return dqkv
+
+
 def row_rnorm(x2d, eps=1e-12):
     require_gpu(x2d)
     rn = torch.empty(x2d.shape[0], device=x2d.device, dtype=torch.float32)
@@ -151,6 +173,46 @@ def transpose_f32(x2d):
 def dropout_apply_(g, seed, p):
     call("simseg_dropout_apply", ptr(_c(g)), dt(g), g.numel(), int(seed), float(p), stream())
     return g
+
+
+def nce_rows(sims, temperature, target0, ignore_mask=None, smoothing=0.0, write_grad=True):
+    """In place: sims <- dLoss/dsims.  Returns out3 = [loss, acc, dLoss/dT] (device tensor)."""
+    require_gpu(sims)
+    N1, N2 = sims.shape
+    scratch = torch.empty(3, N1, device=sims.device, dtype=torch.float32)
+    out3 = torch.empty(3, device=sims.device, dtype=torch.float32)
+    call("simseg_nce_rows", ptr(_c(sims)), ptr(temperature), ptr(_c(ignore_mask)), ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2]),
+         ptr(out3), N1, N2, int(target0), float(smoothing), int(write_grad), stream())
+    return out3
+
+
+def scale_rows(x, s=None, one_minus=False, alpha=1.0, out=None):
+    require_gpu(x)
+    if out is None:
+        out = torch.empty_like(x)
+    D = x.shape[-1]
+    call("simseg_scale_rows", ptr(_c(x)), ptr(_c(s)), ptr(out), x.numel() // D, D, int(one_minus), float(alpha), stream())
+    return out
+
+
+def retrieval_rank(sim, left_gid, right_gid):
+    require_gpu(sim)
+    M, N = sim.shape
+    has = torch.empty(M, device=sim.device, dtype=torch.int32)
+    rank = torch.empty(M, device=sim.device, dtype=torch.int32)
+    call("simseg_retrieval_rank", ptr(_c(sim)), ptr(_c(left_gid)), ptr(_c(right_gid)), ptr(has), ptr(rank), M, N, N, stream())
+    return has, rank
+
+
+def recall_counts(has, rank, bounds=(1, 5, 10)):
+    counts = torch.empty(4, device=has.device, dtype=torch.int32)
+    call("simseg_recall_counts", ptr(has), ptr(rank), has.numel(), int(bounds[0]), int(bounds[1]), int(bounds[2]), ptr(counts), stream())
+    return counts
+
+
+def adamw_step(p, g, m, v, p16, lr, betas, eps, weight_decay, step, grad_scale=1.0):
+    call("simseg_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+         float(eps), float(weight_decay), int(step), float(grad_scale), stream())
 
 
 def tr16_probe():

@@ -199,7 +199,15 @@ def test_topk_pool_l2norm(ops, golden, dtype):
     gy = tt(g["gy"]).cuda()
     ref.backward(gy)
     dtok = ops.topk_pool_l2norm_bwd(gy, emb, norm, idx, tok.shape[1], dtype)
-    _close(dtok, x.grad, tol, "loda pool bwd")
+    if dtype == torch.float32:
+        _close(dtok, x.grad, tol, "loda pool bwd")
+    else:
+        # bf16 token values tie; torch.topk's tie-break is unspecified (SURVEY 7 "hard parts"), so compare the
+        # tie-invariant quantities: gradient mass per channel and the values of the selected tokens
+        _close(dtok.float().sum(1), x.grad.sum(1), tol, "loda pool bwd (mass per channel)")
+        sel = (dtok != 0)
+        assert int(sel.sum(1).max()) <= 5
+        _close((tok.float() * sel).sum(1), tok.float().topk(5, dim=1)[0].sum(1), 1e-5, "selected tokens are the top-5")
     # masked text pooling k=1 (pipelines/clip.py:111-120)
     t, mask = tt(g["t"]).cuda().to(dtype), tt(g["mask"]).cuda()
     temb, tidx, tnorm = ops.topk_pool_l2norm_fwd(t, 1, mask)
@@ -217,3 +225,136 @@ def test_row_rnorm(ops):
     x = _rand(777, 512, seed=1, scale=4.0)
     _close(ops.row_rnorm(x), 1.0 / x.norm(dim=-1).clamp_min(1e-12), 1e-5, "rnorm")
     _close(ops.row_rnorm(x.bfloat16()), 1.0 / x.bfloat16().float().norm(dim=-1).clamp_min(1e-12), 1e-5, "rnorm bf16")
+
+
+def _attn_ref(qkv, H, mask, scale):
+    B, T, _ = qkv.shape
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + (1.0 - mask[:, None, None, :].float()) * -10000.0
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+
+
+@pytest.mark.parametrize("T", [25, 77, 197, 325])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_fwd(ops, T, dtype):
+    B, H = 3, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.5, dtype=dtype)
+    mask = None
+    if T <= 77:       # text shapes: ragged key-padding mask
+        mask = torch.zeros(B, T, dtype=torch.long)
+        for b, n in enumerate((T, 7, 3)):
+            mask[b, :n] = 1
+        mask = mask.cuda()
+    out, lse = ops.attention_fwd(qkv, H, mask, save_lse=True)
+    ref = _attn_ref(qkv, H, mask, 0.125)
+    _close(out, ref, 1e-5 if dtype == torch.float32 else 1.5e-2, f"attention fwd T={T}")
+    q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, -1e30)
+    _close(lse, torch.logsumexp(s, -1) / math.log(2), 1e-5 if dtype == torch.float32 else 1e-2, "lse (log2)")
+
+
+@pytest.mark.parametrize("T", [25, 77, 197, 300])
+def test_attention_bwd(ops, T):
+    B, H = 2, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.2, dtype=torch.bfloat16)
+    dout = _rand(B, T, H * 64, seed=T + 1, dtype=torch.bfloat16)
+    mask = None
+    if T <= 77:
+        mask = torch.zeros(B, T, dtype=torch.long)
+        for b, n in enumerate((T, 9)):
+            mask[b, :n] = 1
+        mask = mask.cuda()
+    out, lse = ops.attention_fwd(qkv, H, mask, save_lse=True)
+    dqkv = ops.attention_bwd(qkv, out, dout, lse, H, mask)
+    x = qkv.float().requires_grad_(True)
+    _attn_ref(x, H, mask, 0.125).backward(dout.float())
+    _close(dqkv, x.grad, 2e-2, f"attention bwd T={T}")
+    if mask is not None:      # padded keys get an exactly-zero K/V gradient
+        g = dqkv.view(B, T, 3, H, 64)
+        assert float(g[1, 9:, 1:].abs().max()) == 0.0
+
+
+def test_attention_dropout(ops):
+    """Dropout on attention probabilities: mean preserved, same mask regenerated by the backward."""
+    B, H, T = 2, 2, 77
+    qkv = _rand(B, T, 3 * H * 64, seed=5, dtype=torch.bfloat16)
+    base, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+    outs = torch.stack([ops.attention_fwd(qkv, H, None, drop_seed=s, drop_p=0.1)[0].float() for s in range(200)])
+    _close(outs.mean(0), base, 0.1, "dropout keeps the expectation")
+    assert not torch.equal(outs[0], outs[1])
+    # backward with dropout == autograd through an explicit masked softmax using the regenerated mask
+    seed, p = 77, 0.1
+    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True, drop_seed=seed, drop_p=p)
+    keep = torch.ones(B * H * T * T, device="cuda")
+    ops.dropout_apply_(keep, seed, p)                      # same hash, same linear index (bh*T + q)*T + key
+    keep = keep.view(B, H, T, T)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-1, -2)) * 0.125).softmax(-1) * keep @ v).transpose(1, 2).reshape(B, T, H * 64)
+    _close(out, ref, 1.5e-2, "dropout fwd vs explicit mask")
+    dout = _rand(B, T, H * 64, seed=6, dtype=torch.bfloat16)
+    ref.backward(dout.float())
+    _close(ops.attention_bwd(qkv, out, dout, lse, H, None, drop_seed=seed, drop_p=p), x.grad, 2e-2, "dropout bwd")
+
+
+@pytest.mark.parametrize("smoothing", [0.0, 0.1])
+def test_nce_rows(ops, smoothing):
+    N1, N2, rank = 24, 96, 2
+    f1 = F.normalize(_rand(N1, 64, seed=1), dim=-1)
+    f2 = F.normalize(_rand(N2, 64, seed=2), dim=-1)
+    ign = torch.zeros(N1, device="cuda"); ign[3] = 1.0
+    temp = torch.tensor(0.05, device="cuda")
+    sims = ops.gemm(f1, f2)
+    s_ref = (f1 @ f2.T).requires_grad_(True)
+    t_ref = temp.clone().requires_grad_(True)
+    z = s_ref / torch.clamp(t_ref, 0.001, 0.5)
+    logp = F.log_softmax(z, -1)
+    tgt = torch.arange(rank * N1, (rank + 1) * N1, device="cuda")
+    loss_rows = (1 - smoothing) * -logp.gather(1, tgt[:, None])[:, 0] + smoothing * -logp.mean(-1)
+    loss = (loss_rows * (1 - ign)).mean()
+    loss.backward()
+    keep = ign < 1
+    acc = (z[keep].argmax(1) == tgt[keep]).float().mean()
+    out3 = ops.nce_rows(sims, temp, rank * N1, ign, smoothing)
+    _close(out3[0], loss.detach(), 1e-5, "nce loss")
+    _close(out3[1], acc, 1e-6, "nce acc")
+    _close(out3[2], t_ref.grad, 1e-4, "nce dtemp")
+    _close(sims, s_ref.grad, 1e-4, "nce dsims")
+    # clamped temperature passes no gradient
+    out3 = ops.nce_rows(ops.gemm(f1, f2), torch.tensor(0.7, device="cuda"), rank * N1, None, 0.0)
+    assert float(out3[2]) == 0.0
+
+
+def test_retrieval_rank(ops, golden):
+    from conftest import tt
+    g = golden("retrieval")
+    img, gi = tt(g["uni_emb"]).cuda(), tt(g["uni_gid"]).cuda()
+    txt, gt = tt(g["txt"]).cuda(), tt(g["gid_txt"]).cuda()
+    for left, lg, right, rg, key in ((img, gi, txt, gt, "i2t"), (txt, gt, img, gi, "t2i")):
+        sim = ops.gemm(left, right)
+        has, rank = ops.retrieval_rank(sim, lg, rg)
+        c = ops.recall_counts(has, rank).cpu().numpy()
+        np.testing.assert_allclose(c[1:] / c[0], g[key], atol=1e-7)
+        s = left @ right.T
+        match = lg[:, None] == rg[None, :]
+        best = torch.where(match, s, torch.full_like(s, -float("inf"))).max(1)[0]
+        assert torch.equal(rank.long(), (s > best[:, None]).sum(1))
+
+
+def test_adamw_step(ops):
+    n = 4096 * 3
+    p, g = _rand(n, seed=1), _rand(n, seed=2)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p16 = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 4):
+        ref.grad = g * step
+        opt.step()
+        ops.adamw_step(p, g * step, m, v, p16, 1e-3, (0.9, 0.98), 1e-6, 1e-3, step)
+    _close(p, ref.detach(), 1e-6, "adamw")
+    assert torch.equal(p16, p.bfloat16())
