@@ -63,11 +63,12 @@ int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, const float* 
 
 /* LoDA pooling + L2norm: emb[b,:] = l2norm(mean over the k largest tokens per channel) with the reference's
  * -10000 overwrite of masked tokens.  simseg/models/components/pooling.py:52-65 + normalization.py:6-11
- * (pipelines/clip.py:87-93,111-120).  idx[B,k,P] and norm[B] are saved for the backward. */
+ * (pipelines/clip.py:87-93,111-120).  idx[B,k,P] and norm[B] are saved for the backward.  normalize=0 returns the
+ * pooled vector itself (TopKPooling used on its own). */
 int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
-                                int64_t B, int64_t N, int64_t P, int k, float eps, void* stream);
+                                int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
-                                int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, void* stream);
+                                int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]
@@ -94,6 +95,9 @@ int simseg_nce_rows(float* sims, const float* temperature, const float* ignore_m
                     void* stream);
 /* y[r,:] = alpha * x[r,:] * (one_minus ? 1 - s[r] : s[r])  -- feat2_global * (1 - ignore_mask), mml_loss.py:70-71. */
 int simseg_scale_rows(const float* x, const float* s, float* y, int64_t rows, int64_t D, int one_minus, float alpha, void* stream);
+
+/* y[i] = alpha * scalar[0] * x[i] with the scalar read on the device (upstream loss gradient, no host sync). */
+int simseg_scale_by_scalar(const float* x, const float* scalar, float* y, int64_t n, float alpha, void* stream);
 
 /* Retrieval: rank[i] = #{j : sim_ij > max_{j': gid match} sim_ij'}, has_match[i] = any gid match.  Equals the
  * argsort/gather/first-match rank of simseg/tasks/clip/hooks/utils.py:36-42,64-66 on tie-free scores. */

@@ -175,6 +175,42 @@ def gold_bert():
     _save("bert_tiny", **out, **sd)
 
 
+def gold_config():
+    """update_cfg results (plain nested dicts, JSON) for both shipped YAMLs with the README's override styles."""
+    import json
+    from simseg.core.config import update_cfg
+    from simseg.tasks.clip.config import task_cfg_init_fn, update_clip_config
+    import simseg.core.config as rc
+
+    def plain(d):
+        return {k: plain(v) if isinstance(v, dict) else (list(v) if isinstance(v, tuple) else v) for k, v in d.items()}
+
+    cases = {
+        "vit-s": ("simseg.vit-s.yaml", []),
+        "vit-b": ("simseg.vit-b.yaml", []),
+        "vit-b-argv": ("simseg.vit-b.yaml", ["data.valid_name=[f30k,coco]", "data.batch_size_val=128", "transforms.input_size=224",
+                                           "loss.temperature.value=0.05", "ckpt.dir=/tmp/x", "model.image_encoder.pretrained=False",
+                                           "optim.lr.init=5e-5", "data.exp_name=abc"]),
+    }
+    out = {}
+    for name, (y, argv) in cases.items():
+        rc.cfg.set_this_dict_immutable(False)
+        out[name] = dict(argv=argv, cfg=plain(update_cfg(task_cfg_init_fn, os.path.join(REF, "configs/clip", y), argv, update_clip_config)))
+    errs = {}
+    for name, argv in {"unknown_key": ["model.nope=1"], "type_mismatch": ["epoch=abc"]}.items():
+        rc.cfg.set_this_dict_immutable(False)
+        try:
+            update_cfg(task_cfg_init_fn, os.path.join(REF, "configs/clip/simseg.vit-b.yaml"), argv, update_clip_config)
+            errs[name] = None
+        except Exception as e:   # noqa: BLE001
+            errs[name] = type(e).__name__
+    out["errors"] = errs
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "config.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote config.json", errs)
+
+
 # ---------------------------------------------------------------------------------------------
 TINY_ARGV = ["transforms.input_size=96", "model.image_encoder.tag=vit_test_patch16",
              "model.image_encoder.embedding_dim=128", "model.image_encoder.pretrained=False",
@@ -311,7 +347,7 @@ def gold_dist(world):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "clip_glue", "dist1", "dist2"]
+    which = sys.argv[1:] or ["config", "heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "clip_glue", "dist1", "dist2"]
     torch.set_num_threads(4)
     _import_reference()
     for w in which:

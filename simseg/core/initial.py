@@ -1,0 +1,39 @@
+"""Process / device initialisation the entry scripts call (mirror of simseg/core/initial.py:37-75).
+One process per GPU; backend 'nccl' is RCCL over xGMI on ROCm.  On a box without GPUs (CPU tests) it falls back to
+gloo so that the collective plumbing can be exercised."""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from simseg.utils import ENV, logger
+
+__all__ = ["init_device"]
+
+
+def init_device(cfg):
+    seed = cfg.seed if cfg.seed is not None else 0
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ENV.cfg = cfg
+    ENV.dist_mode = cfg.dist.name
+    has_gpu = torch.cuda.is_available()
+    if has_gpu:
+        torch.cuda.set_device(ENV.local_rank)
+        torch.cuda.manual_seed_all(seed)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl" if has_gpu else "gloo", init_method="env://")
+    ENV.rank, ENV.size = dist.get_rank(), dist.get_world_size()
+    ENV.device = torch.device("cuda", ENV.local_rank) if has_gpu else torch.device("cpu")
+    for name in ("batch_size", "batch_size_val"):
+        bs = cfg.data.get(name)
+        if isinstance(bs, int) and bs % ENV.size != 0 and bs >= ENV.size:
+            raise AssertionError(f"data.{name}={bs} must be divisible by the world size {ENV.size}")
+    logger.info(f"init_device: rank {ENV.rank}/{ENV.size} on {ENV.device}", root_only=False)

@@ -1,0 +1,139 @@
+"""The drop-in boundary: `CLIPModel` with the reference's attribute / method / state-dict surface
+(simseg/models/pipelines/clip.py:13-229), computing on the MI355X-native towers and heads.
+
+state-dict keys: image_encoder.model.model.* (timm names), text_encoder.model.model.* (HF names),
+image_projection.linear.weight, text_projection.linear.weight, loss.temperature."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from simseg.models.backbones.builder import BACKBONE
+from simseg.models.criteria.losses.builder import LOSS
+from simseg.models.pipelines.builder import PIPELINE
+from simseg.utils import ENV
+from simseg_amd.nn import compute_dtype
+from simseg_amd.towers import ProjectPoolFn
+
+from ..components import AvgPooling, ComplexProjection, L2norm, SimpleProjection, TopKPooling
+from ..components.pooling import clip_k_to_shortest
+
+
+class CLIPModel(nn.Module):
+    def __init__(self, cfg, rank):
+        super().__init__()
+        self.cfg = cfg
+        self.image_encoder = ImageEncoder(cfg)
+        self.text_encoder = TextEncoder(cfg)
+        self.random_seed = np.random.RandomState(seed=2021)
+        heads = {"simple": SimpleProjection, "complex": ComplexProjection}
+        if cfg.model.projection.name not in heads:
+            raise NotImplementedError(cfg.model.projection.name)
+        Head = heads[cfg.model.projection.name]
+        self.image_projection = Head(cfg, embedding_dim=cfg.model.image_encoder.embedding_dim, projection_dim=cfg.model.projection.dim,
+                                     trainable=cfg.model.projection.image_projector_trainable)
+        self.text_projection = Head(cfg, embedding_dim=cfg.model.text_encoder.embedding_dim, projection_dim=cfg.model.projection.dim,
+                                    trainable=cfg.model.projection.text_projector_trainable)
+        if cfg.model.pool.name == "loda":
+            self.text_pool = TopKPooling(cfg.model.pool.loda.text_k, dim=1)
+            self.image_pool = TopKPooling(cfg.model.pool.loda.image_k, dim=1)
+        elif cfg.model.pool.name == "avg":
+            self.text_pool, self.image_pool = AvgPooling(), AvgPooling()
+        else:
+            self.text_pool, self.image_pool = nn.Identity(), nn.Identity()
+        self.loss = LOSS.get(cfg.loss.name)(cfg, rank)
+        self.global_reduce = cfg.loss.global_reduce
+        self.text_target_token_idx = cfg.model.text_encoder.target_token_idx
+        self._fused_heads = cfg.model.pool.name == "loda" and cfg.model.projection.name == "simple"
+
+    # ---- image side ---------------------------------------------------------------------------------------------
+    def forward_image_feature(self, image):
+        """[B,3,H,W] -> patch tokens [B,N,D] (pool != identity) or the [cls] token [B,D] (clip.py:65-84)."""
+        feats = self.image_encoder(image)
+        if self.cfg.model.pool.name == "identity":
+            return feats[:, 0] if feats.dim() == 3 else feats
+        return feats[:, 1:] if feats.dim() == 3 else feats
+
+    def forward_image_project(self, image_features):
+        """projection -> LoDA pool -> L2norm: [B,N,D] -> [B,P] (clip.py:87-93), one fused node."""
+        if self._fused_heads and image_features.dim() == 3:
+            return ProjectPoolFn.apply(image_features, self.image_projection.linear.weight, self.image_pool.k, None, compute_dtype())
+        emb = self.image_pool(self.image_projection(image_features))
+        return L2norm(emb, dim=-1) if self.cfg.model.projection.name == "simple" else emb
+
+    # ---- text side ----------------------------------------------------------------------------------------------
+    def forward_text_feature(self, input_ids, attention_mask):
+        feats = self.text_encoder(input_ids=input_ids, attention_mask=attention_mask)
+        if self.cfg.model.pool.name == "identity":
+            return feats[:, self.text_target_token_idx, :]
+        return feats[:, self.text_target_token_idx:, :]
+
+    def forward_text_project(self, text_features, attention_mask):
+        if self.cfg.model.pool.name == "identity":
+            emb = self.text_pool(self.text_projection(text_features))
+            return L2norm(emb, dim=-1) if self.cfg.model.projection.name == "simple" else emb
+        mask = attention_mask[:, self.text_target_token_idx:] if self.text_target_token_idx else attention_mask
+        if self._fused_heads:
+            k = clip_k_to_shortest(self.text_pool.k, mask)
+            return ProjectPoolFn.apply(text_features, self.text_projection.linear.weight, k, mask.contiguous().long(), compute_dtype())
+        emb = self.text_pool(self.text_projection(text_features), mask)
+        return L2norm(emb, dim=-1) if self.cfg.model.projection.name == "simple" else emb
+
+    # ---- loss / dispatch ----------------------------------------------------------------------------------------
+    def forward_loss(self, image_embeddings, text_embeddings, ignore_mask=None):
+        if self.global_reduce:
+            i2t_loss, i2t_acc = self.loss(image_embeddings, text_embeddings, ignore_mask=ignore_mask)
+            t2i_loss, t2i_acc = self.loss(text_embeddings, image_embeddings, ignore_mask=ignore_mask)
+            loss = 0.5 * (i2t_loss + t2i_loss)
+        else:
+            loss, i2t_acc, t2i_acc = self.loss(image_embeddings, text_embeddings, ignore_mask=ignore_mask)
+        return {f"{self.cfg.loss.name}_loss".lower(): loss}, i2t_acc, t2i_acc
+
+    def forward(self, batch, embeddings=False):
+        if embeddings == "image":
+            return self.forward_image_feature(batch["image"])
+        if embeddings == "text":
+            return self.forward_text_feature(batch["input_ids"], batch["attention_mask"])
+        img = self.forward_image_project(self.forward_image_feature(batch["image"]))
+        txt = self.forward_text_project(self.forward_text_feature(batch["input_ids"], batch["attention_mask"]), batch["attention_mask"])
+        if embeddings == "all":
+            return [img, txt]
+        return self.forward_loss(img, txt, ignore_mask=None)
+
+
+class ImageEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.model_tag = cfg.model.image_encoder.tag
+        self.pretrained = cfg.model.image_encoder.pretrained
+        self.trainable = cfg.model.image_encoder.trainable
+        kwargs = {}
+        if "vit" in self.model_tag:
+            kwargs["img_size"] = cfg.transforms.input_size      # clip.py:193-194
+        else:
+            kwargs["global_pool"] = ""
+        self.model = BACKBONE.get(cfg.model.image_encoder.name)(cfg, **kwargs)
+        for p in self.model.parameters():
+            p.requires_grad = self.trainable
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class TextEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.model_tag = cfg.model.text_encoder.tag
+        self.pretrained = cfg.model.text_encoder.pretrained
+        self.trainable = cfg.model.text_encoder.trainable
+        self.model = BACKBONE.get(cfg.model.text_encoder.name)(cfg)
+        for p in self.model.parameters():
+            p.requires_grad = self.trainable
+
+    def forward(self, input_ids, attention_mask):
+        return self.model(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+
+
+@PIPELINE.register_obj
+def clip(cfg):
+    return CLIPModel(cfg, ENV.rank)

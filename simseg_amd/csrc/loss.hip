@@ -121,6 +121,13 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// y[i] = x[i] * scalar[0] * alpha  (upstream scalar gradient applied without a host round trip)
+__global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y, long n,
+                                       float alpha) {
+    const float f = scalar[0] * alpha;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * f;
+}
+
 // Retrieval (hooks/utils.py:36-42, 64-66): for left row i, best = max_j{sim_ij : gid match}; rank = #{j : sim_ij > best}.
 __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ sim, const long* __restrict__ lgid,
                                                              const long* __restrict__ rgid, int* __restrict__ has,
@@ -206,6 +213,16 @@ extern "C" int simseg_scale_rows(const float* x, const float* s, float* y, int64
     return 0;
 }
 
+extern "C" int simseg_scale_by_scalar(const float* x, const float* scalar, float* y, int64_t n, float alpha, void* stream) {
+    SS_CHECK(x && scalar && y, "scale_by_scalar: null pointer");
+    if (n <= 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, scalar, y, (long)n, alpha);
+    SS_LAUNCH_CHECK("scale_by_scalar");
+    return 0;
+}
+
 extern "C" int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, const int64_t* right_gid, int32_t* has_match,
                                      int32_t* rank, int64_t M, int64_t N, int64_t ld, void* stream) {
     SS_CHECK(sim && left_gid && right_gid && has_match && rank, "retrieval_rank: null pointer");
@@ -219,7 +236,7 @@ extern "C" int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, 
 extern "C" int simseg_recall_counts(const int32_t* has_match, const int32_t* rank, int64_t M, int b0, int b1, int b2,
                                     int32_t* counts4, void* stream) {
     SS_CHECK(has_match && rank && counts4, "recall_counts: null pointer");
-    hipMemsetAsync(counts4, 0, 4 * sizeof(int), STREAM);
+    (void)hipMemsetAsync(counts4, 0, 4 * sizeof(int), STREAM);
     long blocks = (M + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;

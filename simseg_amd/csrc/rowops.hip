@@ -294,7 +294,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 template <typename TI>
 __global__ void topk_pool_fwd_kernel(const TI* __restrict__ tok, const long* __restrict__ mask, float* __restrict__ emb,
-                                     int* __restrict__ idx, float* __restrict__ norm_out, int N, int P, int k, float eps) {
+                                     int* __restrict__ idx, float* __restrict__ norm_out, int N, int P, int k, float eps, int normalize) {
     __shared__ float sh[16];
     const int b = blockIdx.x, c = threadIdx.x;
     float tv[POOL_MAXK];
@@ -318,6 +318,7 @@ __global__ void topk_pool_fwd_kernel(const TI* __restrict__ tok, const long* __r
 #pragma unroll
     for (int j = 0; j < POOL_MAXK; ++j) if (j < k) { s += tv[j]; idx[((long)b * k + j) * P + c] = ti[j]; }
     const float pooled = s / k;
+    if (!normalize) { emb[(long)b * P + c] = pooled; if (c == 0) norm_out[b] = 1.f; return; }
     const float nrm = sqrtf(block_sum(pooled * pooled, sh));
     emb[(long)b * P + c] = pooled / (nrm + eps);
     if (c == 0) norm_out[b] = nrm;
@@ -327,14 +328,17 @@ __global__ void topk_pool_fwd_kernel(const TI* __restrict__ tok, const long* __r
 template <typename TO>
 __global__ void topk_pool_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ emb,
                                      const float* __restrict__ norm, const int* __restrict__ idx, TO* __restrict__ dtok,
-                                     int N, int P, int k, float eps) {
+                                     int N, int P, int k, float eps, int normalize) {
     __shared__ float sh[16];
     const int b = blockIdx.x, c = threadIdx.x;
     const float g = demb[(long)b * P + c], y = emb[(long)b * P + c];
     const float n = norm[b];
-    const float dot = block_sum(g * y, sh);
-    // y = x / (n + eps):  dx = [g - y (g.y)(n+eps)/n] / (n+eps)
-    const float dx = (g - y * dot * (n + eps) / fmaxf(n, 1e-30f)) / (n + eps) / k;
+    float dx = g / k;
+    if (normalize) {
+        const float dot = block_sum(g * y, sh);
+        // y = x / (n + eps):  dx = [g - y (g.y)(n+eps)/n] / (n+eps)
+        dx = (g - y * dot * (n + eps) / fmaxf(n, 1e-30f)) / (n + eps) / k;
+    }
     int sel[POOL_MAXK];
 #pragma unroll
     for (int j = 0; j < POOL_MAXK; ++j) sel[j] = j < k ? idx[((long)b * k + j) * P + c] : -1;
@@ -502,28 +506,28 @@ extern "C" int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, co
 }
 
 extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
-                                           int64_t B, int64_t N, int64_t P, int k, float eps, void* stream) {
+                                           int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream) {
     SS_CHECK(tok && emb && idx && norm, "topk_pool_fwd: null pointer");
     SS_CHECK(P % 64 == 0 && P <= 1024, "topk_pool_fwd: P=%lld must be a multiple of 64 and <= 1024", (long long)P);
     SS_CHECK(k >= 1 && k <= POOL_MAXK && k <= N, "topk_pool_fwd: k=%d out of range (1..%d, <= N)", k, POOL_MAXK);
     if (B <= 0) return 0;
     if (dtype == 0)
-        hipLaunchKernelGGL(topk_pool_fwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const float*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps);
+        hipLaunchKernelGGL(topk_pool_fwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const float*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps, normalize);
     else
-        hipLaunchKernelGGL(topk_pool_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const bf16_t*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps);
+        hipLaunchKernelGGL(topk_pool_fwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, (const bf16_t*)tok, (const long*)mask, emb, idx, norm, (int)N, (int)P, k, eps, normalize);
     SS_LAUNCH_CHECK("topk_pool_fwd");
     return 0;
 }
 
 extern "C" int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
-                                           int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, void* stream) {
+                                           int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream) {
     SS_CHECK(demb && emb && norm && idx && dtok, "topk_pool_bwd: null pointer");
     SS_CHECK(P % 64 == 0 && P <= 1024 && k >= 1 && k <= POOL_MAXK, "topk_pool_bwd: bad P/k");
     if (B <= 0) return 0;
     if (dtype == 0)
-        hipLaunchKernelGGL(topk_pool_bwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (float*)dtok, (int)N, (int)P, k, eps);
+        hipLaunchKernelGGL(topk_pool_bwd_kernel<float>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (float*)dtok, (int)N, (int)P, k, eps, normalize);
     else
-        hipLaunchKernelGGL(topk_pool_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (bf16_t*)dtok, (int)N, (int)P, k, eps);
+        hipLaunchKernelGGL(topk_pool_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (bf16_t*)dtok, (int)N, (int)P, k, eps, normalize);
     SS_LAUNCH_CHECK("topk_pool_bwd");
     return 0;
 }

@@ -1,0 +1,115 @@
+"""Loss / similarity heads on the HIP kernels: differentiable embedding all-gather, global InfoNCE, the dense
+patch x class-text similarity map, and the retrieval recall computation."""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import ops
+
+F32 = torch.float32
+
+
+class GatherLayer(Function):
+    """Differentiable all-gather of [Bl, ...] rows in rank order (simseg/utils/dist.py:323-354).
+    Forward: RCCL all-gather into one [W*Bl, ...] buffer.  Backward: the reference all-reduces the whole gathered
+    gradient and slices its own rows; a reduce-scatter delivers the same rows with 1/W of the traffic."""
+
+    @staticmethod
+    def forward(ctx, tensor, group, rank):
+        ctx.group, ctx.rank, ctx.bl = group, rank, tensor.shape[0]
+        world = dist.get_world_size(group)
+        tensor = tensor.contiguous()
+        out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+        if world == 1:
+            out.copy_(tensor)
+        else:
+            dist.all_gather_into_tensor(out, tensor, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        world = dist.get_world_size(ctx.group)
+        grad = grad.contiguous()
+        if world == 1:
+            return grad.clone(), None, None
+        if dist.get_backend(ctx.group) == "nccl":      # RCCL on ROCm
+            own = torch.empty((ctx.bl,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
+            dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=ctx.group)
+            return own, None, None
+        g = grad.clone()                               # gloo (CPU tests): no reduce_scatter_tensor
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g[ctx.rank * ctx.bl:(ctx.rank + 1) * ctx.bl].clone(), None, None
+
+
+def all_gather_rows(tensor, group):
+    """Non-differentiable variant (simseg/utils/dist.py:65-74, gather_backward=False)."""
+    world = dist.get_world_size(group)
+    tensor = tensor.detach().contiguous()
+    if world == 1:
+        return tensor
+    out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+    dist.all_gather_into_tensor(out, tensor, group=group)
+    return out
+
+
+class NCEFn(Function):
+    """One direction of the global InfoNCE (mml_loss.py:51-103): feat1 [Bl,P] against feat2_global [Bg,P].
+    Returns (loss, top-1 acc) as 0-dim tensors.  The [Bl,Bg] similarity block is produced by the fp32 MFMA GEMM and
+    overwritten in place by its own gradient, so forward+backward touch it twice."""
+
+    @staticmethod
+    def forward(ctx, feat1, feat2g, temperature, ignore, ignore_g, rank, smoothing):
+        f1 = feat1.contiguous().float()
+        f2 = feat2g.contiguous().float()
+        if ignore_g is not None:
+            f2 = ops.scale_rows(f2, ignore_g.contiguous().float(), one_minus=True)       # :70-71
+        sims = ops.gemm(f1, f2)
+        need = any(ctx.needs_input_grad[:3])
+        out3 = ops.nce_rows(sims, temperature.detach().reshape(1).float(), rank * f1.shape[0],
+                            None if ignore is None else ignore.contiguous().float(), smoothing, write_grad=need)
+        ctx.save_for_backward(sims if need else None, f1, f2, out3, ignore_g)
+        loss, acc = out3[0].clone(), out3[1].clone()
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc):
+        ds, f1, f2, out3, ignore_g = ctx.saved_tensors
+        g = gloss.contiguous().float().reshape(1)
+        df1 = df2 = dt = None
+        if ctx.needs_input_grad[0]:
+            df1 = ops.scale_by_scalar(ops.gemm(ds, ops.transpose_f32(f2)), g)
+        if ctx.needs_input_grad[1]:
+            df2 = ops.gemm(ops.transpose_f32(ds), ops.transpose_f32(f1))
+            if ignore_g is not None:
+                df2 = ops.scale_rows(df2, ignore_g.contiguous().float(), one_minus=True)
+            df2 = ops.scale_by_scalar(df2, g)
+        if ctx.needs_input_grad[2]:
+            dt = ops.scale_by_scalar(out3[2:3], g).reshape(())
+        return df1, df2, dt, None, None, None, None
+
+
+def patch_text_similarity(patch_proj, text_feat, eps=1e-12, compute_dtype=F32):
+    """sim[b,n,c] = <normalize(patch_proj[b,n,:]), text_feat[c,:]>  -- the dense zero-shot segmentation map
+    (tools/seg_evaluation.py:112 F.normalize + :136 per-class GEMV, here for every class at once).
+    The row normalisation is fused into the GEMM epilogue as a row scale."""
+    B, N, P = patch_proj.shape
+    x = patch_proj.contiguous().view(B * N, P)
+    rn = ops.row_rnorm(x, eps)
+    t = text_feat.contiguous()
+    if compute_dtype == torch.bfloat16:
+        x, t = (x if x.dtype == torch.bfloat16 else ops.cast(x.float(), torch.bfloat16)), ops.cast(t.float(), torch.bfloat16)
+    else:
+        x, t = x.float(), t.float()
+    return ops.gemm(x, t, rowscale=rn, out_dtype=F32).view(B, N, t.shape[0])
+
+
+def retrieval_recalls(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
+    """R@k of `left` rows retrieving `right` rows sharing their group id (hooks/utils.py:59-75).  One host sync
+    (4 counters), like the reference's .item()."""
+    sim = ops.gemm(left.contiguous().float(), right.contiguous().float())
+    has, rank = ops.retrieval_rank(sim, left_gid.contiguous().long(), right_gid.contiguous().long())
+    c = ops.recall_counts(has, rank, bounds).cpu()
+    if int(c[0]) == 0:
+        raise AssertionError("no left row has a matching right row")
+    return {f"R@{b}": float(c[i + 1]) / float(c[0]) for i, b in enumerate(bounds)}

@@ -108,20 +108,20 @@ def bert_embed_bwd(ids, mask, dsum, dword):
     call("simseg_bert_embed_bwd", ptr(_c(ids)), ptr(_c(mask)), ptr(_c(dsum)), ptr(dword), B, L, dsum.shape[-1], dword.shape[0], stream())
 
 
-def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8):
+def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8, normalize=True):
     require_gpu(tok)
     B, N, P = tok.shape
     emb = torch.empty(B, P, device=tok.device, dtype=torch.float32)
     idx = torch.empty(B, k, P, device=tok.device, dtype=torch.int32)
     norm = torch.empty(B, device=tok.device, dtype=torch.float32)
-    call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), B, N, P, int(k), float(eps), stream())
+    call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), B, N, P, int(k), float(eps), int(normalize), stream())
     return emb, idx, norm
 
 
-def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8):
+def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8, normalize=True):
     B, k, P = idx.shape
     dtok = torch.empty(B, N, P, device=emb.device, dtype=dtype)
-    call("simseg_topk_pool_l2norm_bwd", ptr(_c(demb)), ptr(emb), ptr(norm), ptr(idx), ptr(dtok), dt(dtok), B, N, P, int(k), float(eps), stream())
+    call("simseg_topk_pool_l2norm_bwd", ptr(_c(demb)), ptr(emb), ptr(norm), ptr(idx), ptr(dtok), dt(dtok), B, N, P, int(k), float(eps), int(normalize), stream())
     return dtok
 
 
@@ -192,6 +192,13 @@ def scale_rows(x, s=None, one_minus=False, alpha=1.0, out=None):
         out = torch.empty_like(x)
     D = x.shape[-1]
     call("simseg_scale_rows", ptr(_c(x)), ptr(_c(s)), ptr(out), x.numel() // D, D, int(one_minus), float(alpha), stream())
+    return out
+
+
+def scale_by_scalar(x, scalar, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    call("simseg_scale_by_scalar", ptr(_c(x)), ptr(scalar), ptr(out), x.numel(), float(alpha), stream())
     return out
 
 

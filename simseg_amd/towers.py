@@ -1,0 +1,359 @@
+"""Encoder towers on the HIP kernels: ViT (timm semantics) and BERT (HF semantics), forward in exact-fp32 or bf16,
+backward in bf16 (fp32 accumulate, fp32 master weights/gradients, fp32 residual stream).
+
+Each transformer block is ONE torch.autograd.Function whose backward is written out by hand over the C-ABI ops, so
+that (a) no T x T / intermediate autograd graph exists, (b) parameter gradients of a block are delivered as soon as
+that block's backward finishes -- torch DDP's bucketed RCCL all-reduce overlaps the remaining backward.
+
+Reference arithmetic: timm 0.6.13 VisionTransformer as driven by simseg/models/backbones/mml/vit_builder.py:13-21,
+HF BertModel as driven by huggingface_builder.py:16-17 (both third-party; see oracle/simseg_ref.py)."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _wt(w, adt):
+    """Weight in the activation dtype (bf16 compute copy of the fp32 master, like autocast's per-step cast)."""
+    w = w.detach()
+    return w if adt == F32 else ops.cast(w.contiguous(), BF16)
+
+
+def _splitk(m, n, k_rows):
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    nk = (k_rows + 63) // 64
+    return max(1, min(nk, (1024 + tiles - 1) // tiles, 64))
+
+
+def _wgrad(dy16, x16):
+    """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K."""
+    out_f, in_f = dy16.shape[1], x16.shape[1]
+    dw = torch.zeros(out_f, in_f, device=dy16.device, dtype=F32)
+    ops.gemm(dy16, x16, trans_a=True, trans_b=True, out=dw, accumulate=True, splitk=_splitk(out_f, in_f, dy16.shape[0]))
+    return dw
+
+
+def _bgrad(dy16):
+    db = torch.zeros(dy16.shape[1], device=dy16.device, dtype=F32)
+    ops.colsum_accum(dy16, db)
+    return db
+
+
+def _need_bf16(adt, what):
+    if adt != BF16:
+        raise RuntimeError(f"{what}: the backward pass runs in bf16 compute mode only (enable torch.autocast or set "
+                           "SIMSEG_AMD_COMPUTE=bf16); fp32 mode is forward/eval only")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# generic pieces
+# ------------------------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = x W^T (+ b) on [..., in] -> [..., out]; fp32 in / fp32 out at the module boundary."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, adt):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        xa = x2 if adt == F32 else ops.cast(x2, BF16)
+        wa = _wt(w, adt)
+        y = ops.gemm(xa, wa, bias=None if b is None else b.detach(), out_dtype=F32)
+        ctx.adt, ctx.has_b, ctx.shp = adt, b is not None, shp
+        ctx.save_for_backward(xa, wa)
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        _need_bf16(ctx.adt, "LinearFn")
+        xa, wa = ctx.saved_tensors
+        d16 = ops.cast(dy.reshape(-1, dy.shape[-1]).contiguous(), BF16)
+        dx = ops.gemm(d16, wa, trans_b=True, out_dtype=F32).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(d16, xa) if ctx.needs_input_grad[1] else None
+        db = _bgrad(d16) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        y, _, mean, rstd = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, save_stats=True)
+        ctx.save_for_backward(x, mean, rstd, w.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w = ctx.saved_tensors
+        dg, db = torch.zeros_like(w), torch.zeros_like(w)
+        dx, _ = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), want_bf16=False)
+        return dx, dg, db, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ViT
+# ------------------------------------------------------------------------------------------------------------------
+class ViTEmbedFn(Function):
+    """patch_embed -> cat(cls) -> + pos_embed  (vit_builder.py:14-17) -> fp32 residual stream [B,1+N,D]."""
+
+    @staticmethod
+    def forward(ctx, image, pw, pb, cls, pos, adt):
+        B, _, H, W = image.shape
+        D = pw.shape[0]
+        N = (H // 16) * (W // 16)
+        if pos.shape[1] != N + 1:
+            raise ValueError(f"pos_embed has {pos.shape[1]} tokens but the {H}x{W} input makes {N + 1}")
+        cols = ops.vit_im2col(image.contiguous().float(), adt)
+        w2 = _wt(pw.reshape(D, 768), adt)
+        x = torch.empty(B, N + 1, D, device=image.device, dtype=F32)
+        ops.gemm(cols, w2, bias=pb.detach(), residual=pos.detach().reshape(N + 1, D), row_group=N, res_mod=True, out=x.view(-1, D))
+        ops.vit_cls_rows(cls.detach().reshape(-1), pos.detach().reshape(-1), x)
+        ctx.adt, ctx.dims = adt, (B, N, D)
+        ctx.save_for_backward(cols)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        _need_bf16(ctx.adt, "ViTEmbedFn")
+        (cols,) = ctx.saved_tensors
+        B, N, D = ctx.dims
+        dx = dx.contiguous()
+        dp16 = ops.cast(dx[:, 1:].contiguous().view(-1, D), BF16)
+        dw = _wgrad(dp16, cols).view(D, 3, 16, 16) if ctx.needs_input_grad[1] else None
+        db = _bgrad(dp16) if ctx.needs_input_grad[2] else None
+        dcls = dpos = None
+        if ctx.needs_input_grad[3]:
+            dcls = torch.zeros(D, device=dx.device, dtype=F32)
+            ops.vit_cls_grad(dx, dcls)
+            dcls = dcls.view(1, 1, D)
+        if ctx.needs_input_grad[4]:
+            dpos = torch.zeros((N + 1) * D, device=dx.device, dtype=F32)
+            ops.colsum_accum(dx.view(B, (N + 1) * D), dpos)
+            dpos = dpos.view(1, N + 1, D)
+        return None, dw, db, dcls, dpos, None
+
+
+class ViTBlockFn(Function):
+    """timm Block: x + proj(attn(norm1 x)); then + fc2(gelu(fc1(norm2 .)))   (pre-LN, eps 1e-6, erf GELU)."""
+
+    @staticmethod
+    def forward(ctx, x, heads, adt, n1w, n1b, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+        B, T, D = x.shape
+        x = x.contiguous()
+        save = any(ctx.needs_input_grad)
+        ln1, _, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), 1e-6, out_dtype=adt, save_stats=save)
+        qw_, pw_, f1w_, f2w_ = _wt(qw, adt), _wt(pw, adt), _wt(f1w, adt), _wt(f2w, adt)
+        qkv = ops.gemm(ln1.view(-1, D), qw_, bias=qb.detach())
+        att, lse = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=save)
+        x1 = ops.gemm(att.view(-1, D), pw_, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
+        ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=save)
+        pre = torch.empty(B * T, 4 * D, device=x.device, dtype=adt) if save else None
+        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=1, aux_out=pre)
+        y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
+        ctx.adt, ctx.heads, ctx.dims = adt, heads, (B, T, D)
+        if save:
+            ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_,
+                                  n1w.detach(), n2w.detach())
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _need_bf16(ctx.adt, "ViTBlockFn")
+        x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_, n1w, n2w = ctx.saved_tensors
+        B, T, D = ctx.dims
+        need = ctx.needs_input_grad
+        dy = dy.contiguous().view(-1, D)
+        dy16 = ops.cast(dy, BF16)
+        # mlp
+        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=2, aux=pre)
+        df2w = _wgrad(dy16, act) if need[13] else None
+        df2b = _bgrad(dy16) if need[14] else None
+        dln2 = ops.gemm(dpre, f1w_, trans_b=True)
+        df1w = _wgrad(dpre, ln2) if need[11] else None
+        df1b = _bgrad(dpre) if need[12] else None
+        dn2w, dn2b = torch.zeros_like(n2w), torch.zeros_like(n2w)
+        dx1_32, dx1_16 = ops.layernorm_bwd(x1, mean2, rstd2, n2w, dn2w, dn2b, dy16=dln2, dres=dy)
+        # attention
+        datt = ops.gemm(dx1_16, pw_, trans_b=True)
+        dpw = _wgrad(dx1_16, att.view(-1, D)) if need[7] else None
+        dpb = _bgrad(dx1_16) if need[8] else None
+        dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5).view(-1, 3 * D)
+        dln1 = ops.gemm(dqkv, qw_, trans_b=True)
+        dqw = _wgrad(dqkv, ln1.view(-1, D)) if need[5] else None
+        dqb = _bgrad(dqkv) if need[6] else None
+        dn1w, dn1b = torch.zeros_like(n1w), torch.zeros_like(n1w)
+        dx, _ = ops.layernorm_bwd(x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dy16=dln1, dres=dx1_32, want_bf16=False)
+        return (dx.view(B, T, D), None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
+
+
+def vit_forward(m, image, adt):
+    """m: module tree with timm parameter names (see simseg_amd/nn.py ViT). Returns all tokens after the final LN."""
+    x = ViTEmbedFn.apply(image, m.patch_embed.proj.weight, m.patch_embed.proj.bias, m.cls_token, m.pos_embed, adt)
+    for blk in m.blocks:
+        x = ViTBlockFn.apply(x, m.num_heads, adt, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
+                             blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
+                             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+    return LayerNormFn.apply(x, m.norm.weight, m.norm.bias, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BERT
+# ------------------------------------------------------------------------------------------------------------------
+class BertEmbedFn(Function):
+    """HF BertEmbeddings: LN(word[ids] + pos[:L] + type[0]) -> dropout."""
+
+    @staticmethod
+    def forward(ctx, ids, mask, word, pos, typ, lnw, lnb, drop_p, seed):
+        B, L = ids.shape
+        if L > pos.shape[0]:
+            raise ValueError(f"sequence length {L} exceeds max_position_embeddings {pos.shape[0]}")
+        s = ops.bert_embed_fwd(ids.contiguous(), word.detach(), pos.detach(), typ.detach()[0].contiguous())
+        y, _, mean, rstd = ops.layernorm_fwd(s, lnw.detach(), lnb.detach(), 1e-12, save_stats=True)
+        if drop_p > 0:
+            ops.dropout_apply_(y, seed, drop_p)
+        ctx.drop = (drop_p, seed)
+        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        ctx.save_for_backward(ids, mask, s, mean, rstd, lnw.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, mask, s, mean, rstd, lnw = ctx.saved_tensors
+        B, L = ids.shape
+        D = s.shape[-1]
+        dy = dy.contiguous()
+        if ctx.drop[0] > 0:
+            dy = ops.dropout_apply_(dy.clone(), ctx.drop[1], ctx.drop[0])
+        dg, db = torch.zeros_like(lnw), torch.zeros_like(lnw)
+        ds, _ = ops.layernorm_bwd(s, mean, rstd, lnw, dg, db, dy32=dy, want_bf16=False)
+        wshape, pshape, tshape = ctx.shapes
+        dword = dpos = dtyp = None
+        if ctx.needs_input_grad[2]:
+            dword = torch.zeros(wshape, device=dy.device, dtype=F32)
+            ops.bert_embed_bwd(ids, mask, ds, dword)
+        if ctx.needs_input_grad[3]:
+            dpos = torch.zeros(pshape, device=dy.device, dtype=F32)
+            ops.colsum_accum(ds.view(B, L * D), dpos.view(-1)[: L * D])
+        if ctx.needs_input_grad[4]:
+            dtyp = torch.zeros(tshape, device=dy.device, dtype=F32)
+            ops.colsum_accum(ds.view(B * L, D), dtyp[0])
+        return None, None, dword, dpos, dtyp, dg, db, None, None
+
+
+class BertLayerFn(Function):
+    """HF BertLayer (post-LN, eps 1e-12): a = LN(x + drop(dense(attn(x)))); y = LN(a + drop(dense(gelu(dense(a)))))."""
+
+    @staticmethod
+    def forward(ctx, x, mask, heads, adt, drop_p, seed, qw, qb, kw, kb, vw, vb, ow, ob, law, lab, iw, ib, o2w, o2b, low, lob):
+        B, L, D = x.shape
+        x = x.contiguous()
+        save = any(ctx.needs_input_grad)
+        xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
+        wqkv = torch.empty(3 * D, D, device=x.device, dtype=adt)
+        for i, w in enumerate((qw, kw, vw)):
+            if adt == F32:
+                wqkv[i * D:(i + 1) * D].copy_(w.detach())
+            else:
+                ops.cast(w.detach().contiguous(), BF16, out=wqkv[i * D:(i + 1) * D])
+        bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
+        ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
+        qkv = ops.gemm(xa, wqkv, bias=bqkv)
+        att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p)
+        s1 = ops.gemm(att.view(-1, D), ow_, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
+        a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
+        aa = a32 if adt == F32 else a16
+        pre = torch.empty(B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
+        act = ops.gemm(aa, iw_, bias=ib.detach(), act=1, aux_out=pre)
+        s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
+        y, _, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, save_stats=save)
+        ctx.adt, ctx.heads, ctx.dims, ctx.drop = adt, heads, (B, L, D), (drop_p, seed)
+        if save:
+            ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
+                                  law.detach(), low.detach())
+        return y.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _need_bf16(ctx.adt, "BertLayerFn")
+        (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low) = ctx.saved_tensors
+        B, L, D = ctx.dims
+        p, seed = ctx.drop
+        need = ctx.needs_input_grad
+        dy = dy.contiguous().view(-1, D)
+        dlow, dlob = torch.zeros_like(low), torch.zeros_like(low)
+        ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy)
+        if p > 0:
+            ops.dropout_apply_(d2, seed + 2, p)
+        dpre = ops.gemm(d2, o2w_, trans_b=True, act=2, aux=pre)
+        do2w = _wgrad(d2, act) if need[18] else None
+        do2b = _bgrad(d2) if need[19] else None
+        da = ops.gemm(dpre, iw_, trans_b=True)
+        diw = _wgrad(dpre, aa) if need[16] else None
+        dib = _bgrad(dpre) if need[17] else None
+        dlaw, dlab = torch.zeros_like(law), torch.zeros_like(law)
+        ds1_32, d1 = ops.layernorm_bwd(s1, mean_a, rstd_a, law, dlaw, dlab, dy16=da, dy32=ds2_32)
+        if p > 0:
+            ops.dropout_apply_(d1, seed + 1, p)
+        datt = ops.gemm(d1, ow_, trans_b=True)
+        dow = _wgrad(d1, att.view(-1, D)) if need[12] else None
+        dob = _bgrad(d1) if need[13] else None
+        dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), att, datt.view(B, L, D), lse, ctx.heads, mask, scale=64 ** -0.5,
+                                 drop_seed=seed, drop_p=p).view(-1, 3 * D)
+        dx = ops.gemm(dqkv, wqkv, trans_b=True, residual=ds1_32, out_dtype=F32)
+        dwqkv = _wgrad(dqkv, xa) if (need[6] or need[8] or need[10]) else None
+        dbqkv = _bgrad(dqkv) if (need[7] or need[9] or need[11]) else None
+        dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]
+        dbs = [dbqkv[i * D:(i + 1) * D] if dbqkv is not None else None for i in range(3)]
+        return (dx.view(B, L, D), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dow, dob, dlaw, dlab,
+                diw, dib, do2w, do2b, dlow, dlob)
+
+
+def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
+    """m: module tree with HF BertModel parameter names (simseg_amd/nn.py Bert). Returns last_hidden_state [B,L,D] fp32."""
+    p_h = m.hidden_dropout_prob if training else 0.0
+    p_a = m.attention_probs_dropout_prob if training else 0.0
+    if p_h != p_a:
+        raise NotImplementedError("hidden and attention dropout probabilities are expected to be equal (HF default 0.1)")
+    e = m.embeddings
+    mask = attention_mask.contiguous().long()
+    x = BertEmbedFn.apply(input_ids, mask, e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
+                          e.LayerNorm.weight, e.LayerNorm.bias, p_h, seed)
+    for i, lyr in enumerate(m.encoder.layer):
+        a, s = lyr.attention, lyr.attention.self
+        x = BertLayerFn.apply(x, mask, m.num_heads, adt, p_h, seed + 16 * (i + 1),
+                              s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+                              a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
+                              lyr.intermediate.dense.weight, lyr.intermediate.dense.bias,
+                              lyr.output.dense.weight, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# heads
+# ------------------------------------------------------------------------------------------------------------------
+class ProjectPoolFn(Function):
+    """SimpleProjection -> TopKPooling(LoDA) -> L2norm  (pipelines/clip.py:87-93, 111-120) as one node:
+    the [B,N,512] token projection lives only inside this function."""
+
+    @staticmethod
+    def forward(ctx, feats, w, k, mask, adt):
+        B, N, D = feats.shape
+        f2 = feats.contiguous().view(-1, D)
+        fa = f2 if adt == F32 else ops.cast(f2, BF16)
+        wa = _wt(w, adt)
+        tok = ops.gemm(fa, wa).view(B, N, w.shape[0])
+        emb, idx, norm = ops.topk_pool_l2norm_fwd(tok, k, mask)
+        ctx.adt, ctx.k, ctx.dims = adt, k, (B, N, D)
+        ctx.save_for_backward(fa, wa, emb, idx, norm)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        _need_bf16(ctx.adt, "ProjectPoolFn")
+        fa, wa, emb, idx, norm = ctx.saved_tensors
+        B, N, D = ctx.dims
+        dtok = ops.topk_pool_l2norm_bwd(demb.contiguous(), emb, norm, idx, N, BF16).view(B * N, -1)
+        dfe = ops.gemm(dtok, wa, trans_b=True, out_dtype=F32).view(B, N, D) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(dtok, fa) if ctx.needs_input_grad[1] else None
+        return dfe, dw, None, None, None

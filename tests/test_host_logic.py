@@ -1,0 +1,83 @@
+"""CPU tests of the host-side mirror: config surface, registries, state-dict layout, C-ABI exports."""
+import ctypes
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLD, REPO
+
+
+def _plain(d):
+    return {k: _plain(v) if isinstance(v, dict) else (list(v) if isinstance(v, tuple) else v) for k, v in d.items()}
+
+
+def _cfg(yaml_name, argv):
+    from simseg.core.config import update_cfg
+    from simseg.tasks.clip.config import task_cfg_init_fn, update_clip_config
+    return update_cfg(task_cfg_init_fn, os.path.join(REPO, "configs/clip", yaml_name), argv, update_clip_config)
+
+
+def test_config_matches_reference_golden():
+    gold = json.load(open(os.path.join(GOLD, "config.json")))
+    for name, yaml_name in (("vit-s", "simseg.vit-s.yaml"), ("vit-b", "simseg.vit-b.yaml"), ("vit-b-argv", "simseg.vit-b.yaml")):
+        got = _plain(_cfg(yaml_name, gold[name]["argv"]))
+        assert got == gold[name]["cfg"], name
+    assert gold["errors"] == {"unknown_key": "ValueError", "type_mismatch": "ValueError"}
+    with pytest.raises(ValueError):
+        _cfg("simseg.vit-b.yaml", ["model.nope=1"])
+    with pytest.raises(ValueError):
+        _cfg("simseg.vit-b.yaml", ["epoch=abc"])
+
+
+def test_config_frozen_and_unknown_yaml_key(tmp_path):
+    c = _cfg("simseg.vit-b.yaml", [])
+    with pytest.raises(AttributeError):
+        c.epoch = 3
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("model:\n  no_such_key: 1\n")
+    from simseg.core.config import update_cfg
+    from simseg.tasks.clip.config import task_cfg_init_fn
+    with pytest.raises(KeyError, match="Non-existent config key: model.no_such_key"):
+        update_cfg(task_cfg_init_fn, str(bad), [])
+
+
+TINY = ["transforms.input_size=96", "model.image_encoder.tag=vit_test_patch16", "model.image_encoder.embedding_dim=128",
+        "model.image_encoder.pretrained=False", "model.text_encoder.tag=bert-test", "model.text_encoder.embedding_dim=128",
+        "model.text_encoder.pretrained=False"]
+
+
+def test_registries_and_state_dict_layout(golden):
+    from simseg.models import BACKBONE, LOSS, PIPELINE
+    from simseg.utils import build_from_cfg
+    assert PIPELINE.has("clip") and BACKBONE.has("vit_modelzoo") and BACKBONE.has("huggingface_modelzoo") and LOSS.has("NCE")
+    cfg = _cfg("simseg.vit-s.yaml", TINY)
+    model = build_from_cfg(cfg.model.name, cfg, PIPELINE)
+    g = golden("clip_glue")
+    ref_keys = {k[3:] for k in g.files if k.startswith("sd.")}
+    ours = {k: v for k, v in model.state_dict().items()}
+    assert ref_keys <= set(ours), sorted(ref_keys - set(ours))[:5]
+    assert {k for k in ours if k not in ref_keys} == {"text_encoder.model.model.embeddings.position_ids"}
+    for k in ref_keys:
+        assert tuple(ours[k].shape) == tuple(g["sd." + k].shape), k
+    vit = model.image_encoder.model.model
+    assert vit.patch_embed.num_patches == 36 and tuple(vit.pos_embed.shape) == (1, 37, 128)
+    assert model.loss.temperature.dim() == 0 and isinstance(model.loss.temperature, torch.nn.Parameter)
+    # the product path has no CPU fallback: a forward on CPU tensors must fail loudly
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        model.forward_image_feature(torch.zeros(1, 3, 96, 96))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from simseg_amd import lib
+    decl = lib.parse_header()
+    assert len(decl) >= 25
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in decl:
+        assert hasattr(so, name), f"{name} declared in include/simseg_hip.h but not exported"
+    l = lib.load()
+    assert l.simseg_version() >= 100
+    # argument validation happens before any device work: callable without a GPU
+    assert l.simseg_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, 0, 0, None, None, 0, 0, 0, 1, 0, 0.0, None) != 0
+    assert b"null operand" in l.simseg_last_error()
