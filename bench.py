@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Benchmark of the SimSeg hot path on MI355X (contract in the task statement / SURVEY.md 8d).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+Workload (BASELINE.json configs[2], weak-scaled): ViT-B/16 + BERT-base contrastive pre-training step on synthetic
+CC3M-shaped pairs -- 512 pairs per GPU, 224x224 images, 77-token captions -- forward, global InfoNCE (RCCL embedding
+all-gather / reduce-scatter), backward, DDP gradient all-reduce and the AdamW step, all inside the timed region.
+Compute dtype bf16 (fp32 accumulate, fp32 master weights / residual stream), matching the reference's autocast recipe.
+One step = one pass of the hot path over one batch; value = pairs/s over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16 = 2.5e15      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12
+
+
+def flops_per_pair(n_patches, dim, seq, proj=512):
+    """Algorithmic FLOPs of one image-text pair, fwd+bwd = 3x fwd."""
+    t = n_patches + 1
+    f_vit = 12 * (24 * t * dim * dim + 4 * t * t * dim) + 2 * n_patches * 768 * dim
+    f_bert = 12 * (24 * seq * 768 * 768 + 4 * seq * seq * 768)
+    f_proj = 2 * n_patches * dim * proj + 2 * seq * 768 * proj
+    return 3 * (f_vit + f_bert + f_proj)
+
+
+def build_model(tag, dim, img, rank_argv=()):
+    from simseg.core.config import update_cfg
+    from simseg.models import PIPELINE
+    from simseg.tasks.clip.config import task_cfg_init_fn, update_clip_config
+    from simseg.utils import build_from_cfg
+    argv = [f"transforms.input_size={img}", f"model.image_encoder.tag={tag}", f"model.image_encoder.embedding_dim={dim}",
+            "model.image_encoder.pretrained=False", "model.text_encoder.pretrained=False"] + list(rank_argv)
+    cfg = update_cfg(task_cfg_init_fn, os.path.join(REPO, "configs/clip/simseg.vit-b.yaml"), argv, update_clip_config)
+    return cfg, build_from_cfg
+
+
+def synthetic_batch(B, img, L, vocab, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, img, img, generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    ids = torch.randint(1000, vocab, (B, L), generator=g)
+    pos = torch.arange(L)[None]
+    mask = (pos < lens[:, None]).long()
+    ids = ids * mask
+    ids[:, 0] = 101
+    ids[torch.arange(B), lens - 1] = 102
+    return {"image": image.to(device), "input_ids": ids.to(device), "attention_mask": mask.to(device)}
+
+
+def cpu_baseline(img, L, budget_s=20.0):
+    """The oracle (a torch fp32 restatement of the reference stack) doing the same training step on the host cores."""
+    from oracle import simseg_ref as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    B = 4
+    ref = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=img), seed=2).train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    b = synthetic_batch(B, img, L, 30522, 7, "cpu")
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = ref.forward_loss_local(b["image"], b["input_ids"], b["attention_mask"])
+        loss.backward()
+        opt.step()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} fwd+bwd+AdamW steps of {B} pairs (ViT-B/16 @{img}, BERT-base L={L}) with the torch-fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=512)
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--seq-len", type=int, default=77)
+    ap.add_argument("--tag", default="vit_base_patch16_224_in21k")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    from simseg.utils import ENV
+    ENV.local_rank = local
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.img, args.seq_len)
+
+    from simseg.core import init_device
+    from simseg_amd import ops
+    from simseg_amd.nn import VIT_ARCH
+    from simseg_amd.optim import AdamW
+    dim = VIT_ARCH[args.tag]["dim"]
+    cfg, build = build_model(args.tag, dim, args.img)
+    init_device(cfg)                                   # RCCL process group (env://), ENV.rank/size/device
+    from simseg.models import PIPELINE
+    torch.manual_seed(1234)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
+    opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    B, L = args.pairs_per_gpu, args.seq_len
+    batch = synthetic_batch(B, args.img, L, 30522, 1000 + rank, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss_dict, _, _ = net(batch)
+        loss_dict["nce_loss"].backward()
+        opt.step()
+        return loss_dict["nce_loss"]
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+
+    # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
+    ops.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    agg = {}
+    for kind, fl, e0, e1 in ops.PROFILE:
+        a = agg.setdefault(kind, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
+    ops.PROFILE = None
+
+    if rank == 0:
+        n_patches = (args.img // 16) ** 2
+        fpp = flops_per_pair(n_patches, dim, L)
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        dom = max(agg, key=lambda k: agg[k][2])
+        cnt, fl, sec = agg[dom]
+        achieved = fl / sec / 1e12
+        gemm_sec = sum(a[2] for a in agg.values())
+        out = {
+            "metric": "image-text pairs/sec (train)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 + BERT-base contrastive pretrain step (fwd + global InfoNCE + bwd + AdamW), "
+                                   f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
+                       "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
+                       "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
+                       "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel<{dom}> (32x32x16 bf16 MFMA, 128x128 tile)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
+                         "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
+                         "flops_per_launch_avg": fl / cnt},
+            "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),
+                           "whole_step_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
+                           "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
+                           "gemm_time_share": round(gemm_sec / (elapsed / args.steps), 3),
+                           "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
+                           "final_loss": round(float(loss), 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ template <> struct TT<float> { static constexpr int EPC = 4, BK = 32; };
 template <> struct TT<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 
 // ---- global -> register staging ----------------------------------------------------------------
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, bool AL = true>
 __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const T* __restrict__ base, long ld, int row0, int lim,
                                           int k0, int K, int tid) {
     constexpr int EPC = TT<T>::EPC;
@@ -64,7 +64,20 @@ __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const T* __restrict__ b
         u32x4 v = {0u, 0u, 0u, 0u};
         if (!TRANS) {
             const int rr = row0 + (idx >> 3), kk = k0 + (idx & 7) * EPC;
-            if (rr < lim && kk < K) v = *reinterpret_cast<const u32x4*>(base + (long)rr * ld + kk);
+            if constexpr (AL) {
+                if (rr < lim && kk < K) v = *reinterpret_cast<const u32x4*>(base + (long)rr * ld + kk);
+            } else {            // arbitrary K / leading dimension (fp32 only): element loads with a K bound
+                static_assert(sizeof(T) == 4 || AL, "unaligned path is fp32 only");
+                if (rr < lim) {
+                    const T* src = base + (long)rr * ld + kk;
+                    union { u32x4 q; T e[EPC]; } u;
+                    u.q = v;
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j)
+                        if (kk + j < K) u.e[j] = src[j];
+                    v = u.q;
+                }
+            }
         } else {
             const int kr = k0 + (idx >> 4), mm = row0 + (idx & 15) * 8;
             if (kr < K && mm < lim) v = *reinterpret_cast<const u32x4*>(base + (long)kr * ld + mm);
@@ -122,7 +135,7 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b)
 template <typename TO> __device__ __forceinline__ float ld_out(const TO* p) { return (float)*p; }
 template <typename TO> __device__ __forceinline__ void st_out(TO* p, float v) { *p = (TO)v; }
 
-template <typename T, typename TO, bool TA, bool TB>
+template <typename T, typename TO, bool TA, bool TB, bool AL = true>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
     char* ldsA = lds;
@@ -153,16 +166,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 
     u32x4 ra[4], rb[4];
     if (kt0 < kt1) {
-        load_tile<T, TA>(ra, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
-        load_tile<T, TB>(rb, B, p.ldb, n0, p.N, kt0 * BK, p.K, tid);
+        load_tile<T, TA, AL>(ra, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
+        load_tile<T, TB, AL>(rb, B, p.ldb, n0, p.N, kt0 * BK, p.K, tid);
     }
     for (int kt = kt0; kt < kt1; ++kt) {
         store_tile<TA>(ra, ldsA, tid);
         store_tile<TB>(rb, ldsB, tid);
         __syncthreads();
         if (kt + 1 < kt1) {
-            load_tile<T, TA>(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
-            load_tile<T, TB>(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+            load_tile<T, TA, AL>(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+            load_tile<T, TB, AL>(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T, typename TO, bool TA, bool TB>
+template <typename T, typename TO, bool TA, bool TB, bool AL = true>
 int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int BK = TT<T>::BK;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -236,7 +249,7 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     if (q.ksplit < 1) q.ksplit = 1;
     const int z = nk > 0 ? (nk + q.ksplit - 1) / q.ksplit : 1;
     dim3 grid(tiles, 1, z);
-    hipLaunchKernelGGL((gemm_kernel<T, TO, TA, TB>), grid, dim3(NTHREADS), 0, stream, q);
+    hipLaunchKernelGGL((gemm_kernel<T, TO, TA, TB, AL>), grid, dim3(NTHREADS), 0, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm");
     return 0;
 }
@@ -258,11 +271,11 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     SS_CHECK(in_dtype == 1 || out_dtype == 0, "simseg_gemm: fp32 operands produce fp32 output");
     SS_CHECK(in_dtype == 1 || (!transA && !transB), "simseg_gemm: transposed operands need bf16");
     SS_CHECK(!(transA && !transB), "simseg_gemm: (transA, !transB) is not on the path");
-    SS_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "simseg_gemm: operands must be 16-byte aligned");
-    SS_CHECK(lda % epc == 0 && ldb % epc == 0, "simseg_gemm: lda/ldb must be multiples of %d elements", epc);
-    // the contiguous extent of every operand is fetched in 16-byte chunks
-    SS_CHECK((transA ? M : K) % epc == 0, "simseg_gemm: contiguous extent of A must be a multiple of %d", epc);
-    SS_CHECK((transB ? N : K) % epc == 0, "simseg_gemm: contiguous extent of B must be a multiple of %d", epc);
+    // operands are fetched in 16-byte chunks along their contiguous extent; fp32 has an element-wise fallback
+    const bool aligned = ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && lda % epc == 0 && ldb % epc == 0 &&
+                         (transA ? M : K) % epc == 0 && (transB ? N : K) % epc == 0;
+    SS_CHECK(aligned || in_dtype == 0, "simseg_gemm: bf16 operands need 16-byte aligned pointers and contiguous extents / leading dimensions that are multiples of 8");
+    SS_CHECK(((uintptr_t)A % 4) == 0 && ((uintptr_t)B % 4) == 0, "simseg_gemm: misaligned operand");
     SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f),
              "simseg_gemm: split-K needs a plain fp32 accumulate epilogue");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "simseg_gemm: dropout p out of range");
@@ -278,7 +291,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == 0) return launch<float, float, false, false>(p, splitk, s);
+    if (in_dtype == 0) return aligned ? launch<float, float, false, false, true>(p, splitk, s) : launch<float, float, false, false, false>(p, splitk, s);
     if (!transA && !transB) return out_dtype ? launch<bf16_t, bf16_t, false, false>(p, splitk, s) : launch<bf16_t, float, false, false>(p, splitk, s);
     if (!transA && transB) return out_dtype ? launch<bf16_t, bf16_t, false, true>(p, splitk, s) : launch<bf16_t, float, false, true>(p, splitk, s);
     return out_dtype ? launch<bf16_t, bf16_t, true, true>(p, splitk, s) : launch<bf16_t, float, true, true>(p, splitk, s);

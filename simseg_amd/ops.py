@@ -21,6 +21,9 @@ def _c(t):
     return t
 
 
+PROFILE = None   # bench.py sets this to a list to time every GEMM launch with events on the launch stream
+
+
 def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, rowscale=None,
          residual=None, act=0, aux=None, aux_out=None, row_group=0, res_mod=False, accumulate=False, splitk=1,
          drop_seed=0, drop_p=0.0, out_rows=None):
@@ -37,10 +40,17 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         out = torch.empty(rows, N, device=a.device, dtype=out_dtype or a.dtype)
     _c(out)
     ldr = residual.shape[-1] if residual is not None else 0
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("simseg_gemm", ptr(a), ptr(b), ptr(out), M, N, K, a.shape[1], b.shape[1], out.shape[-1], dt(a), dt(out),
          int(trans_a), int(trans_b), float(alpha), ptr(_c(bias)), ptr(_c(rowscale)), ptr(_c(residual)), ldr, int(act),
          ptr(_c(aux)), ptr(_c(aux_out)), int(row_group), int(res_mod), int(accumulate), int(splitk), int(drop_seed),
          float(drop_p), stream())
+    if PROFILE is not None:
+        e1.record()
+        kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
+        PROFILE.append((kind, 2.0 * M * N * K, e0, e1))
     return out
 
 

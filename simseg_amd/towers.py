@@ -311,6 +311,8 @@ class BertLayerFn(Function):
 
 def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     """m: module tree with HF BertModel parameter names (simseg_amd/nn.py Bert). Returns last_hidden_state [B,L,D] fp32."""
+    if training and (m.hidden_dropout_prob > 0 or m.attention_probs_dropout_prob > 0):
+        _need_bf16(adt, "BERT in train() mode (dropout)")
     p_h = m.hidden_dropout_prob if training else 0.0
     p_a = m.attention_probs_dropout_prob if training else 0.0
     if p_h != p_a:

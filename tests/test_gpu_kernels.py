@@ -42,7 +42,8 @@ def test_tr16_probe_layout(ops):
     assert np.array_equal(m, want), f"unexpected tr16 layout:\n{m[:16]}"
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (788, 1152, 384), (325, 21, 512), (4, 512, 128), (1000, 264, 40)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (788, 1152, 384), (325, 21, 512), (4, 512, 128), (1000, 264, 40),
+                                   (3, 512, 3), (130, 7, 45), (512, 3, 1)])
 def test_gemm_f32_nt(ops, M, N, K):
     a, b = _rand(M, K, seed=1), _rand(N, K, seed=2)
     _close(ops.gemm(a, b), a @ b.T, 1e-5, f"f32 NT {M}x{N}x{K}")

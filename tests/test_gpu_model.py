@@ -134,6 +134,10 @@ def test_fp32_mode_refuses_backward(golden, monkeypatch):
     g = golden("clip_train_ws1")
     m = _build(golden)
     batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    with pytest.raises(RuntimeError, match="bf16 compute mode only"):     # train() mode: refused at the first dropout site
+        m.train()
+        m(batch)
+    m.eval()
     loss = m(batch)[0]["nce_loss"]
     with pytest.raises(RuntimeError, match="bf16 compute mode only"):
         loss.backward()
