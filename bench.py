@@ -26,6 +26,13 @@ PEAK_BF16 = 2.5e15      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.m
 PEAK_F32 = 157.3e12
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def flops_per_pair(n_patches, dim, seq, proj=512):
     """Algorithmic FLOPs of one image-text pair, fwd+bwd = 3x fwd."""
     t = n_patches + 1
@@ -62,8 +69,10 @@ def synthetic_batch(B, img, L, vocab, seed, device):
 def cpu_baseline(img, L, budget_s=20.0):
     """The oracle (a torch fp32 restatement of the reference stack) doing the same training step on the host cores."""
     from oracle import simseg_ref as R
-    torch.set_num_threads(os.cpu_count() or 1)
-    B = 4
+    # a bounded thread count: the GPU box reports 256 logical CPUs but oversubscribing them made round-1's first
+    # baseline run 100x slower than 8 threads in the build container
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    B = 2
     ref = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=img), seed=2).train()
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
     b = synthetic_batch(B, img, L, 30522, 7, "cpu")
@@ -74,9 +83,12 @@ def cpu_baseline(img, L, budget_s=20.0):
         loss.backward()
         opt.step()
 
+    t_warm = time.perf_counter()
     step()
+    t_warm = time.perf_counter() - t_warm
+    log(f"cpu_baseline: warm-up step of {B} pairs took {t_warm:.1f}s on {torch.get_num_threads()} threads")
     n, t0 = 0, time.perf_counter()
-    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
+    while n < 1 or (time.perf_counter() - t0 + t_warm < budget_s and n < 20):
         step()
         n += 1
     dt = time.perf_counter() - t0
@@ -110,6 +122,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.img, args.seq_len)
 
+    log("cpu baseline done" if cpu else "no cpu baseline")
     from simseg.core import init_device
     from simseg_amd import ops
     from simseg_amd.nn import VIT_ARCH
@@ -126,6 +139,7 @@ def main():
     opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
     B, L = args.pairs_per_gpu, args.seq_len
     batch = synthetic_batch(B, args.img, L, 30522, 1000 + rank, dev)
+    log("model and batch on device")
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -134,8 +148,11 @@ def main():
         opt.step()
         return loss_dict["nce_loss"]
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -149,6 +166,7 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
     ops.PROFILE = []
@@ -188,12 +206,13 @@ def main():
                            "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
                            "gemm_time_share": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
-                           "final_loss": round(float(loss), 4)},
+                           "final_loss": round(float(loss.detach()), 4)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

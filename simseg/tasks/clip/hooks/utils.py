@@ -1,0 +1,46 @@
+"""Retrieval metric with the reference's call surface (simseg/tasks/clip/hooks/utils.py:9-75), computed by the fused
+similarity GEMM + first-match-rank kernels instead of an M x N argsort and an int64 gid gather."""
+from dataclasses import dataclass
+from typing import Any, Dict
+
+import torch
+
+from simseg_amd.heads import retrieval_recalls
+
+__all__ = ["IndexedEmbInfo", "EmbANN", "RetrievalMetric"]
+
+
+@dataclass
+class IndexedEmbInfo:
+    emb_name: str
+    group_idx: torch.Tensor  # [N]
+    emb_mat: torch.Tensor    # [N, D]
+
+    def unique(self):
+        """One row per group id, keeping the last row of every run after a sort by id (utils.py:14-19)."""
+        gid, order = torch.sort(self.group_idx)
+        uni, count = torch.unique_consecutive(gid, return_counts=True)
+        last = torch.cumsum(count, 0) - 1
+        return IndexedEmbInfo(self.emb_name, uni, self.emb_mat[order][last])
+
+    def to_chunks(self, chunk_size):
+        for s in range(0, self.emb_mat.shape[0], chunk_size):
+            yield IndexedEmbInfo(self.emb_name, self.group_idx[s:s + chunk_size], self.emb_mat[s:s + chunk_size])
+
+
+class EmbANN:
+    def __init__(self, chunk_size=None):
+        raise NotImplementedError("EmbANN's sorted-gid matrices are never materialised here; use RetrievalMetric")
+
+
+class RetrievalMetric:
+    def __init__(self, with_prefix=True):
+        self.recall_range = (1, 5, 10)
+        self.with_prefix = with_prefix
+
+    def __call__(self, leftemb: IndexedEmbInfo, rightemb: IndexedEmbInfo) -> Dict[str, Any]:
+        res = retrieval_recalls(leftemb.emb_mat, leftemb.group_idx, rightemb.emb_mat, rightemb.group_idx, self.recall_range)
+        if self.with_prefix:
+            prefix = f"[{leftemb.emb_name}] to [{rightemb.emb_name}]:"
+            res = {f"{prefix} {k}": v for k, v in res.items()}
+        return res

@@ -1,0 +1,78 @@
+"""world_size-2 tests of the multi-process path on CPU (gloo): the differentiable embedding gather (all-gather forward,
+reduce-scatter-equivalent backward), group construction and the plain gather helpers.  The loss arithmetic between the
+collectives is the oracle's here (the HIP loss kernel needs a GPU); what is pinned is the exchange step, against the
+gradients the REFERENCE's GatherLayer + NCE produced in a 2-process run (tests/golden/clip_train_ws2.npz)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLD, REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import simseg_ref as R
+    from simseg.utils import ENV, GatherLayer, all_gather, concat_all_gather
+    from simseg.utils.dist import generate_local_groups
+    ENV.rank, ENV.size, ENV.local_rank = rank, world, rank
+    g = np.load(os.path.join(GOLD, f"clip_train_ws{world}.npz"))
+    f1 = torch.from_numpy(g[f"r{rank}.nce_f1"]).requires_grad_(True)
+    f2 = torch.from_numpy(g[f"r{rank}.nce_f2"]).requires_grad_(True)
+    ign = torch.from_numpy(g[f"r{rank}.nce_ign"])
+    temp = torch.tensor(0.02, requires_grad=True)
+    group, grank = generate_local_groups(world)
+    assert grank == rank
+    f2g = GatherLayer.apply(f2, group, grank)
+    ign_g = torch.cat(all_gather(ign))
+    loss, acc = R.nce_global(f1, f2g, temp, grank, ign, ign_g)
+    loss.backward()
+    res = dict(loss=loss.item(), acc=acc.item(), g1=f1.grad.numpy(), g2=f2.grad.numpy(), gt=temp.grad.item(),
+               want_loss=float(g[f"r{rank}.nce_loss"]), want_acc=float(g[f"r{rank}.nce_acc"]), want_g1=g[f"r{rank}.nce_g1"],
+               want_g2=g[f"r{rank}.nce_g2"], want_gt=float(g[f"r{rank}.nce_gt"]))
+    # sub-groups of size 1: every rank is alone, the gather is the identity
+    sub, sub_rank = generate_local_groups(1)
+    res["sub"] = (dist.get_world_size(sub), sub_rank)
+    res["cat"] = concat_all_gather(torch.full((2,), float(rank))).tolist()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gather_layer_matches_reference_two_ranks(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = out[r]
+        np.testing.assert_allclose(o["loss"], o["want_loss"], rtol=2e-5)
+        np.testing.assert_allclose(o["acc"], o["want_acc"], atol=1e-6)
+        np.testing.assert_allclose(o["g1"], o["want_g1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o["g2"], o["want_g2"], rtol=1e-4, atol=1e-6)     # summed over both ranks' losses
+        np.testing.assert_allclose(o["gt"], o["want_gt"], rtol=1e-4)
+        assert o["sub"] == (1, 0)
+        assert o["cat"] == [0.0, 0.0, 1.0, 1.0]

@@ -164,3 +164,27 @@ def test_full_size_vs_oracle(monkeypatch):
         got_t = bert(ids.cuda(), mask.cuda()).last_hidden_state
     assert _maxerr(got_i, want_i) < 1e-3 and _maxerr(got_t, want_t) < 1e-3
     print("full-size fp32 max errs:", _maxerr(got_i, want_i), _maxerr(got_t, want_t))
+
+
+def test_retrieval_metric_mirror_vs_reference_golden(golden):
+    """IndexedEmbInfo.unique + RetrievalMetric both directions == the reference's numbers (hooks/utils.py)."""
+    from simseg.tasks.clip.hooks.utils import IndexedEmbInfo, RetrievalMetric
+    g = golden("retrieval")
+    img = IndexedEmbInfo("image", tt(g["gid_rows"]).cuda(), tt(g["img_rows"]).cuda()).unique()
+    assert torch.equal(img.group_idx.cpu(), tt(g["uni_gid"])) and torch.equal(img.emb_mat.cpu(), tt(g["uni_emb"]))
+    txt = IndexedEmbInfo("text", tt(g["gid_txt"]).cuda(), tt(g["txt"]).cuda())
+    m = RetrievalMetric()
+    i2t, t2i = m(img, txt), m(txt, img)
+    np.testing.assert_allclose([i2t[f"[image] to [text]: R@{k}"] for k in (1, 5, 10)], g["i2t"], atol=1e-7)
+    np.testing.assert_allclose([t2i[f"[text] to [image]: R@{k}"] for k in (1, 5, 10)], g["t2i"], atol=1e-7)
+
+
+def test_seg_similarity_map_vs_reference_golden(golden, monkeypatch):
+    """Dense patch x class-text similarity (tools/seg_evaluation.py:112,136) for all classes at once."""
+    from simseg_amd.heads import patch_text_similarity
+    g = golden("seg_block")
+    sim = patch_text_similarity(tt(g["proj"]).cuda(), tt(g["text"]).cuda())           # [B, N, C]
+    maps = sim.transpose(1, 2).reshape(2, 21, 18, 18)
+    assert _maxerr(maps, tt(g["maps"])) < 1e-5
+    sim16 = patch_text_similarity(tt(g["proj"]).cuda(), tt(g["text"]).cuda(), compute_dtype=torch.bfloat16)
+    assert _maxerr(sim16, sim) < 2e-2

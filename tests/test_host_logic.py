@@ -81,3 +81,37 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens before any device work: callable without a GPU
     assert l.simseg_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, 0, 0, None, None, 0, 0, 0, 1, 0, 0.0, None) != 0
     assert b"null operand" in l.simseg_last_error()
+
+
+def test_interpolate_pos_embed_and_miou_match_reference(golden):
+    import types
+    import numpy as np
+    from conftest import tt
+    from simseg.utils import interpolate_pos_embed, mean_iou
+    g = golden("interp_pe")
+    for n in (18, 32):
+        enc = types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=n * n), pos_embed=torch.zeros(1, 1 + n * n, 96))
+        torch.testing.assert_close(interpolate_pos_embed(tt(g["pe"]).clone(), enc), tt(g[f"pe_{n}"]), rtol=1e-6, atol=1e-6)
+    same = types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=196), pos_embed=torch.zeros(1, 197, 96))
+    assert interpolate_pos_embed(tt(g["pe"]), same) is not None and interpolate_pos_embed(tt(g["pe"]), same).shape[1] == 197
+    g = golden("miou")
+    for i in range(3):
+        inter, union = mean_iou([g["pred"][i]], [g["gt"][i]], 21, 255)
+        np.testing.assert_allclose(inter.numpy(), g["inter"][i])
+        np.testing.assert_allclose(union.numpy(), g["union"][i])
+
+
+def test_get_dist_state_dict_and_key_helpers():
+    from simseg.core.hooks.checkpoint import get_dist_state_dict
+    from simseg.utils import ENV, convert_keys, filter_state
+    sd = {"image_encoder.model.model.cls_token": 1, "loss.temperature": 2}
+    old = ENV.dist_mode
+    try:
+        ENV.dist_mode = "torch"
+        assert list(get_dist_state_dict(sd)) == ["module.image_encoder.model.model.cls_token", "module.loss.temperature"]
+        ENV.dist_mode = None
+        assert get_dist_state_dict(sd) is sd
+    finally:
+        ENV.dist_mode = old
+    assert list(filter_state(sd, remove_prefixes=("loss.",))) == ["image_encoder.model.model.cls_token"]
+    assert list(convert_keys(sd, [["image_encoder.", "img."]])) == ["img.model.model.cls_token", "loss.temperature"]
