@@ -35,6 +35,9 @@ int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int
                 const float* rowscale, const float* residual, int64_t ldr, int act, const void* aux, void* aux_out,
                 int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, void* stream);
 
+/* Kernel selection for benchmarking: 0 auto, 1 128x128 register-staged, 2 256x256 BK64x2, 3 256x256 BK32x4 ring. */
+int simseg_set_gemm_variant(int v);
+
 /* LayerNorm over the last dim of x[rows,D] (fp32 residual stream) -> y (out_dtype) and optionally a bf16 copy.
  * Saves mean/rstd when non-null.  Replaces nn.LayerNorm in timm Block.norm1/norm2/VisionTransformer.norm
  * (eps 1e-6) and HF Bert*Output.LayerNorm / BertEmbeddings.LayerNorm (eps 1e-12). */

@@ -135,8 +135,165 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b)
 template <typename TO> __device__ __forceinline__ float ld_out(const TO* p) { return (float)*p; }
 template <typename TO> __device__ __forceinline__ void st_out(TO* p, float v) { *p = (TO)v; }
 
+// ---- epilogue -------------------------------------------------------------------------------------------------
+// The 32x32 MFMA accumulator layout gives a lane ONE column and 16 scattered rows, so storing it directly means
+// 2-byte (bf16) stores, 64 per lane: measured store-issue bound (a K=768 GEMM spent ~half its time there).  Instead each
+// wave stages a 32-row x 64-column fp32 block of its accumulators in a private LDS scratch area and re-reads it
+// row-major, 8 consecutive columns per lane: bias / GELU / residual / dropout run on 8-wide vectors and every global
+// access (store, residual load, pre-activation load/save) is 16 bytes per lane, whole 128/256-byte row segments per
+// 8 lanes.
+constexpr int EP_PITCH = 68;                       // floats per staged row (64 + 4 pad)
+constexpr int EP_WAVE_FLOATS = 32 * EP_PITCH;      // 8704 B per wave
+
+template <typename TO> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        union { u32x4 q; bf16x8 h; } u;
+        u.q = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)u.h[e];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        union { u32x4 q; bf16x8 h; } u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u.h[e] = (bf16_t)v[e];
+        *reinterpret_cast<u32x4*>(p) = u.q;
+    }
+};
+
+// Emits rows [row0, row0+32) x cols [col0, col0+64) from two 32x32 accumulators (left/right 32 columns).
+template <typename TO>
+__device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16& accL, const f32x16& accR, float* wlds, int row0,
+                                               int col0, int lane, bool atomic, bool vec_ok) {
+    const int h2 = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h2;
+        wlds[rr * EP_PITCH + cl] = accL[r];
+        wlds[rr * EP_PITCH + 32 + cl] = accR[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TO* C = static_cast<TO*>(p.C);
+    const TO* aux = static_cast<const TO*>(p.aux);
+    TO* aux_out = static_cast<TO*>(p.aux_out);
+    if constexpr (sizeof(TO) == 4) {
+        if (atomic) {      // split-K partial: plain alpha-scaled accumulate, one row of 64 consecutive floats per instruction
+            const int col = col0 + lane;
+            if (col < p.N) {
+                for (int rr = 0; rr < 32; ++rr) {
+                    const int row = row0 + rr;
+                    if (row >= p.M) break;
+                    atomicAdd(reinterpret_cast<float*>(C) + (long)row * p.ldc + col, wlds[rr * EP_PITCH + lane] * p.alpha);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = lane + 64 * t;
+        const int rr = q >> 3, c8 = (q & 7) * 8;
+        const int row = row0 + rr, col = col0 + c8;
+        if (row >= p.M || col >= p.N) continue;
+        float v[8];
+        {
+            const float4 a = *reinterpret_cast<const float4*>(wlds + rr * EP_PITCH + c8);
+            const float4 b = *reinterpret_cast<const float4*>(wlds + rr * EP_PITCH + c8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        const float rs = p.alpha * (p.rowscale ? p.rowscale[row] : 1.0f);
+        long orow = row;
+        if (p.row_group > 0) orow = (long)(row / p.row_group) * (p.row_group + 1) + 1 + row % p.row_group;
+        const long o = orow * p.ldc + col;
+        const long ro = p.residual ? (p.res_mod ? (long)(1 + row % p.row_group) : orow) * p.ldr + col : 0;
+        const bool full = vec_ok && col + 8 <= p.N;
+        if (full) {
+            if (p.bias) {
+                float b[8];
+                Vec8<float>::load(p.bias + col, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * rs + b[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs;
+            }
+            if (p.act == 1) {
+                if (aux_out) Vec8<TO>::store(aux_out + o, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            } else if (p.act == 2) {
+                float a[8];
+                Vec8<TO>::load(aux + o, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(a[e]);
+            }
+            if (p.drop_thresh) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + col + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+            }
+            if (p.residual) {
+                float a[8];
+                Vec8<float>::load(p.residual + ro, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += a[e];
+            }
+            if constexpr (sizeof(TO) == 4) {
+                if (p.accumulate) {
+                    float a[8];
+                    Vec8<float>::load(reinterpret_cast<const float*>(C) + o, a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += a[e];
+                }
+            }
+            Vec8<TO>::store(C + o, v);
+        } else {
+            for (int e = 0; e < 8 && col + e < p.N; ++e) {
+                float x = v[e] * rs + (p.bias ? p.bias[col + e] : 0.f);
+                if (p.act == 1) {
+                    if (aux_out) st_out(aux_out + o + e, x);
+                    x = gelu_erf(x);
+                } else if (p.act == 2) {
+                    x *= dgelu_erf(ld_out(aux + o + e));
+                }
+                if (p.drop_thresh) x = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + col + e, p.drop_thresh) ? x * p.drop_scale : 0.f;
+                if (p.residual) x += p.residual[ro + e];
+                if constexpr (sizeof(TO) == 4) {
+                    if (p.accumulate) x += ld_out(C + o + e);
+                }
+                st_out(C + o + e, x);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// 16-byte vector accesses need aligned bases and leading dimensions
+__device__ __forceinline__ bool epilogue_vec_ok(const GemmParams& p, int out_elem_bytes) {
+    bool ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C) % 16 == 0);
+    if (p.residual) ok = ok && (p.ldr % 4 == 0) && (((uintptr_t)p.residual) % 16 == 0);
+    if (p.bias) ok = ok && (((uintptr_t)p.bias) % 16 == 0);
+    if (p.aux) ok = ok && (((uintptr_t)p.aux) % 16 == 0);
+    if (p.aux_out) ok = ok && (((uintptr_t)p.aux_out) % 16 == 0);
+    return ok;
+}
+
 template <typename T, typename TO, bool TA, bool TB, bool AL = true>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
     char* ldsA = lds;
     char* ldsB = lds + TILE_BYTES;
@@ -192,49 +349,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane%32, row = (r%4) + 8*(r/4) + 4*(lane/32)
-    TO* C = static_cast<TO*>(p.C);
-    const TO* aux = static_cast<const TO*>(p.aux);
-    TO* aux_out = static_cast<TO*>(p.aux_out);
+    // ---- epilogue (the main loop's trailing barrier has released the operand tiles: reuse them as scratch)
     const bool atomic = gridDim.z > 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-            const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.rowscale) v *= p.rowscale[row];
-                v += bias;
-                long orow = row;
-                if (p.row_group > 0) orow = (long)(row / p.row_group) * (p.row_group + 1) + 1 + row % p.row_group;
-                const long o = orow * p.ldc + col;
-                if (p.act == 1) {
-                    if (aux_out) st_out(aux_out + o, v);
-                    v = gelu_erf(v);
-                } else if (p.act == 2) {
-                    v *= dgelu_erf(ld_out(aux + o));
-                }
-                if (p.drop_thresh) {
-                    v = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + col, p.drop_thresh) ? v * p.drop_scale : 0.f;
-                }
-                if (p.residual) {
-                    const long rrow = p.res_mod ? 1 + row % p.row_group : orow;
-                    v += p.residual[rrow * p.ldr + col];
-                }
-                if constexpr (sizeof(TO) == 4) {
-                    if (atomic) { atomicAdd(reinterpret_cast<float*>(C) + o, v); continue; }
-                    if (p.accumulate) v += ld_out(C + o);
-                }
-                st_out(C + o, v);
-            }
-        }
-    }
+    const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
+    float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
+    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 64, n0 + wn * 64, lane, atomic, vec_ok);
+    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 64 + 32, n0 + wn * 64, lane, atomic, vec_ok);
 }
 
 template <typename T, typename TO, bool TA, bool TB, bool AL = true>
@@ -254,6 +374,197 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
+
+// =================================================================================================================
+// Large-tile bf16 kernel: 256x256 block tile, 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA 32x32 accumulators.
+// Operand K-slabs go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging) into
+// a ring of NSTAGE slabs of BKE k-elements each, so NSTAGE-1 slabs are in flight while one is consumed; one raw
+// s_barrier per slab and counted vmcnt waits (never a full drain in steady state).  The LDS image is lane-linear, so
+// the bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the fragment read:
+//   k-contiguous slab  [256 rows][BKE*2 B]: 16-B slot s of row r holds k-chunk  s ^ f(r)
+//   transposed slab    [BKE k-rows][512 B]: 16-B slot s of k-row kr holds m-chunk s ^ ((kr & 3) << 2)
+// Requirements: bf16 operands, K % BKE == 0, 16-byte aligned contiguous extents (else the 128x128 kernel is used).
+// =================================================================================================================
+constexpr int LT = 256;                 // tile edge
+constexpr int LTHREADS = 512;
+
+template <int BKE> __device__ __forceinline__ int kc_swz(int r) { return BKE == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
+// issue the global->LDS copies of one operand slab for this wave.  NI = 1-KiB pieces per wave.
+template <int BKE, bool TRANS>
+__device__ __forceinline__ void glds_slab(const bf16_t* __restrict__ base, long ld, int row0, int lim, int k0, char* lds_slab,
+                                          int wave, int lane) {
+    constexpr int SLAB = LT * BKE * 2;
+    constexpr int NI = SLAB / 1024 / 8;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int piece = wave * NI + i;
+        const bf16_t* src;
+        if (!TRANS) {
+            constexpr int SPR = BKE / 8;                 // 16-B slots per row
+            constexpr int RPP = 64 / SPR;                // rows per 1-KiB piece
+            const int r = piece * RPP + lane / SPR;
+            const int c = (lane % SPR) ^ kc_swz<BKE>(r);
+            int gr = row0 + r;
+            gr = gr < lim ? gr : lim - 1;                // rows past the edge re-read the last row; never stored
+            src = base + (long)gr * ld + k0 + c * 8;
+        } else {
+            const int kr = piece * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            int gc = row0 + c * 8;
+            gc = gc < lim ? gc : lim - 8;
+            src = base + (long)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_slab + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int BKE, bool TRANS>
+__device__ __forceinline__ u32x4 read_frag_l(const char* slab, int row32, int kk, int lane) {
+    if (!TRANS) {
+        const int r = row32 + (lane & 31);
+        const int c = 2 * kk + (lane >> 5);
+        return *reinterpret_cast<const u32x4*>(slab + r * (BKE * 2) + ((c ^ kc_swz<BKE>(r)) << 4));
+    } else {
+        const int a = lane & 15;
+        const int mm = row32 + ((lane >> 4) & 1) * 16 + (a & 3) * 4;
+        const int kr = kk * 16 + (lane >> 5) * 8 + (a >> 2);
+        const char* p = slab + kr * 512 + (((mm >> 3) ^ ((kr & 3) << 2)) << 4) + (mm & 7) * 2;
+        typedef s16x4 __attribute__((address_space(3))) * lptr;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * 512));
+        union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
+        u.s.lo = lo; u.s.hi = hi;
+        return u.v;
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename TO, bool TA, bool TB, int BKE, int NSTAGE>
+__global__ __launch_bounds__(LTHREADS) void gemm_large_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SLAB = LT * BKE * 2;              // bytes of one operand slab
+    constexpr int LPS = 2 * (SLAB / 1024 / 8);      // global_load_lds issued per wave per stage (A + B)
+    constexpr int KSTEPS = BKE / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = (p.N + LT - 1) / LT;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (t / tiles_n) * LT, n0 = (t % tiles_n) * LT;
+    const int nk = p.K / BKE;
+    const int kt0 = blockIdx.z * p.ksplit;
+    const int kt1 = min(nk, kt0 + p.ksplit);
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+
+    f32x16 acc[4][2];
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = zero;
+    }
+
+    // prologue: fill NSTAGE-1 stages
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        if (kt0 + s < kt1) {
+            glds_slab<BKE, TA>(A, p.lda, m0, p.M, (kt0 + s) * BKE, lds + (2 * s) * SLAB, wave, lane);
+            glds_slab<BKE, TB>(B, p.ldb, n0, p.N, (kt0 + s) * BKE, lds + (2 * s + 1) * SLAB, wave, lane);
+        }
+    }
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // slab kt must have landed; up to NSTAGE-2 younger slabs may stay in flight
+        const int ahead = min(NSTAGE - 2, kt1 - 1 - kt);
+        if (NSTAGE >= 4 && ahead >= 2) wait_vm<2 * LPS>();
+        else if (NSTAGE >= 3 && ahead >= 1) wait_vm<LPS>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int nxt = kt + NSTAGE - 1;
+        if (nxt < kt1) {
+            int ns = stage + NSTAGE - 1; ns = ns >= NSTAGE ? ns - NSTAGE : ns;
+            glds_slab<BKE, TA>(A, p.lda, m0, p.M, nxt * BKE, lds + (2 * ns) * SLAB, wave, lane);
+            glds_slab<BKE, TB>(B, p.ldb, n0, p.N, nxt * BKE, lds + (2 * ns + 1) * SLAB, wave, lane);
+        }
+        const char* sa = lds + (2 * stage) * SLAB;
+        const char* sb = sa + SLAB;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            u32x4 fa[4], fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag_l<BKE, TB>(sb, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag_l<BKE, TA>(sa, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma<bf16_t>(acc[i][j], fa[i], fb[j]);
+        }
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+    const bool atomic = gridDim.z > 1;
+    const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
+    __builtin_amdgcn_s_barrier();                       // every wave is done with the operand ring: reuse it as scratch
+    float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
+    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 128, n0 + wn * 64, lane, atomic, vec_ok);
+    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 128 + 32, n0 + wn * 64, lane, atomic, vec_ok);
+    epilogue_block<TO>(p, acc[2][0], acc[2][1], wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane, atomic, vec_ok);
+    epilogue_block<TO>(p, acc[3][0], acc[3][1], wlds, m0 + wm * 128 + 96, n0 + wn * 64, lane, atomic, vec_ok);
+}
+
+template <typename TO, bool TA, bool TB, int BKE, int NSTAGE>
+int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
+    constexpr int SMEM = NSTAGE * 2 * LT * BKE * 2;
+    static bool configured = false;
+    auto kern = gemm_large_kernel<TO, TA, TB, BKE, NSTAGE>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
+        configured = true;
+    }
+    const int tiles = ((p.M + LT - 1) / LT) * ((p.N + LT - 1) / LT);
+    const int nk = p.K / BKE;
+    GemmParams q = p;
+    if (splitk < 1) splitk = 1;
+    if (splitk > nk) splitk = nk;
+    q.ksplit = (nk + splitk - 1) / splitk;
+    const int z = (nk + q.ksplit - 1) / q.ksplit;
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, z), dim3(LTHREADS), SMEM, stream, q);
+    SS_LAUNCH_CHECK("simseg_gemm(large)");
+    return 0;
+}
+
+// variant: 0 = auto, 1 = force the 128x128 kernel, 2 = 256x256 BK64 x2 stages, 3 = 256x256 BK32 x4 stages
+int g_gemm_variant = 0;
+
+template <typename TO, bool TA, bool TB>
+int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
+    const bool big_ok = aligned && p.K % 64 == 0 && p.M >= 256 && p.N >= 128;
+    int v = g_gemm_variant;
+    const int nk64 = p.K / 64;
+    const int kper = (nk64 + (splitk > 1 ? splitk : 1) - 1) / (splitk > 1 ? splitk : 1);   // 64-deep slabs per block
+    // measured (profiles/r1_gemm_variants.txt): the 256x256 tile wins for k-contiguous A once its fixed cost is amortised
+    // over >= 48 slabs (K >= 3072); split-K wgrad and K = 768 are faster on the 128x128 kernel (3 blocks/CU overlap)
+    if (v == 0) v = (big_ok && !TA && kper >= 48) ? 2 : 1;
+    if (!big_ok) v = 1;
+    if (v == 2) return launch_large<TO, TA, TB, 64, 2>(p, splitk, s);
+    if (v == 3) return launch_large<TO, TA, TB, 32, 4>(p, splitk, s);
+    return launch<bf16_t, TO, TA, TB>(p, splitk, s);
+}
+
+}  // namespace
+
+extern "C" int simseg_set_gemm_variant(int v) {
+    g_gemm_variant = v;
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 // dtype codes: 0 = fp32, 1 = bf16
@@ -292,7 +603,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype == 0) return aligned ? launch<float, float, false, false, true>(p, splitk, s) : launch<float, float, false, false, false>(p, splitk, s);
-    if (!transA && !transB) return out_dtype ? launch<bf16_t, bf16_t, false, false>(p, splitk, s) : launch<bf16_t, float, false, false>(p, splitk, s);
-    if (!transA && transB) return out_dtype ? launch<bf16_t, bf16_t, false, true>(p, splitk, s) : launch<bf16_t, float, false, true>(p, splitk, s);
-    return out_dtype ? launch<bf16_t, bf16_t, true, true>(p, splitk, s) : launch<bf16_t, float, true, true>(p, splitk, s);
+    if (!transA && !transB) return out_dtype ? dispatch_bf16<bf16_t, false, false>(p, splitk, aligned, s) : dispatch_bf16<float, false, false>(p, splitk, aligned, s);
+    if (!transA && transB) return out_dtype ? dispatch_bf16<bf16_t, false, true>(p, splitk, aligned, s) : dispatch_bf16<float, false, true>(p, splitk, aligned, s);
+    return out_dtype ? dispatch_bf16<bf16_t, true, true>(p, splitk, aligned, s) : dispatch_bf16<float, true, true>(p, splitk, aligned, s);
 }

@@ -21,6 +21,11 @@ def _c(t):
     return t
 
 
+def set_gemm_variant(v):
+    """0 auto, 1 128x128 register-staged kernel, 2 256x256 BK64 x2 stages, 3 256x256 BK32 x4-stage ring."""
+    call("simseg_set_gemm_variant", int(v))
+
+
 PROFILE = None   # bench.py sets this to a list to time every GEMM launch with events on the launch stream
 
 

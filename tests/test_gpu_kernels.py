@@ -85,6 +85,26 @@ def test_gemm_bf16_layouts(ops, ta, tb, M, N, K):
     _close(ops.gemm(a, b, trans_a=ta, trans_b=tb), ref, 1e-2, f"bf16 ta={ta} tb={tb} bf16 out")
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 520, 192), (256, 136, 64), (2048, 768, 768)])
+def test_gemm_bf16_large_tile_kernel(ops, variant, ta, tb, M, N, K):
+    """The 256x256 direct-to-LDS kernels (swizzled LDS image, counted vmcnt ring) on interior and edge tiles."""
+    ops.set_gemm_variant(variant)
+    try:
+        a = _rand(*((K, M) if ta else (M, K)), seed=1, dtype=torch.bfloat16)
+        b = _rand(*((K, N) if tb else (N, K)), seed=2, dtype=torch.bfloat16)
+        ref = (a.float().T if ta else a.float()) @ (b.float() if tb else b.float().T)
+        _close(ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32), ref, 1e-5, f"large v{variant} ta={ta} tb={tb}")
+        bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+        _close(ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32), ref + bias + res, 1e-5, "large + epilogue")
+        acc = torch.zeros(M, N, device="cuda")
+        ops.gemm(a, b, trans_a=ta, trans_b=tb, out=acc, accumulate=True, splitk=3)
+        _close(acc, ref, 2e-5, "large split-K")
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_gemm_bf16_splitk_and_dgelu(ops):
     K, M, N = 5000, 256, 384          # wgrad shape: contraction over rows
     dy, x = _rand(K, M, seed=1, dtype=torch.bfloat16), _rand(K, N, seed=2, dtype=torch.bfloat16)

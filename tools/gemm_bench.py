@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Micro-benchmark of simseg_gemm on the shapes of the ViT-B / BERT-base training step (512 pairs per GPU).
+    python tools/gemm_bench.py [--shapes train|quick] [--iters 20] [--only nt|nn|tn]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simseg_amd import ops  # noqa: E402
+
+MV, MB = 512 * 197, 512 * 77
+SHAPES = {
+    "train": [
+        ("nt", MV, 2304, 768), ("nt", MV, 768, 768), ("nt", MV, 3072, 768), ("nt", MV, 768, 3072), ("nt", MB, 2304, 768), ("nt", MB, 3072, 768),
+        ("nn", MV, 768, 2304), ("nn", MV, 768, 768), ("nn", MV, 3072, 768), ("nn", MV, 768, 3072), ("nn", MB, 768, 3072),
+        ("tn", 2304, 768, MV), ("tn", 768, 768, MV), ("tn", 3072, 768, MV), ("tn", 768, 3072, MV), ("tn", 3072, 768, MB),
+    ],
+    "quick": [("nt", MV, 3072, 768), ("nt", MV, 768, 3072), ("nn", MV, 768, 3072), ("tn", 3072, 768, MV)],
+    "square": [("nt", 4096, 4096, 4096), ("nt", 8192, 8192, 8192)],
+}
+
+
+def run(kind, M, N, K, iters, out_f32=False):
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    ta, tb = kind == "tn", kind in ("nn", "tn")
+    a = torch.randn((K, M) if ta else (M, K), device=dev, generator=g).bfloat16()
+    b = torch.randn((K, N) if tb else (N, K), device=dev, generator=g).bfloat16()
+    kw = dict(trans_a=ta, trans_b=tb)
+    if kind == "tn":
+        out = torch.zeros(M, N, device=dev)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        kw.update(out=out, accumulate=True, splitk=max(1, min((K + 63) // 64, (1024 + tiles - 1) // tiles, 64)))
+    elif out_f32:
+        kw.update(out_dtype=torch.float32)
+    for _ in range(3):
+        ops.gemm(a, b, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(a, b, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="train")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--variant", type=int, default=0)
+    args = ap.parse_args()
+    ops.set_gemm_variant(args.variant)
+    tot_ms = tot_fl = 0.0
+    for kind, M, N, K in SHAPES[args.shapes]:
+        if args.only and kind != args.only:
+            continue
+        ms, tf = run(kind, M, N, K, args.iters)
+        tot_ms += ms; tot_fl += 2.0 * M * N * K
+        print(f"{kind} M={M:6d} N={N:5d} K={K:6d}  {ms:8.3f} ms  {tf:8.1f} TFLOP/s", flush=True)
+    print(f"sum {tot_ms:.3f} ms  -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
