@@ -385,17 +385,17 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
 //   transposed slab    [BKE k-rows][512 B]: 16-B slot s of k-row kr holds m-chunk s ^ ((kr & 3) << 2)
 // Requirements: bf16 operands, K % BKE == 0, 16-byte aligned contiguous extents (else the 128x128 kernel is used).
 // =================================================================================================================
-constexpr int LT = 256;                 // tile edge
 constexpr int LTHREADS = 512;
 
 template <int BKE> __device__ __forceinline__ int kc_swz(int r) { return BKE == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
-// issue the global->LDS copies of one operand slab for this wave.  NI = 1-KiB pieces per wave.
-template <int BKE, bool TRANS>
+// issue the global->LDS copies of one operand slab (ROWS tile rows/cols x BKE k) for this wave
+template <int BKE, bool TRANS, int ROWS>
 __device__ __forceinline__ void glds_slab(const bf16_t* __restrict__ base, long ld, int row0, int lim, int k0, char* lds_slab,
                                           int wave, int lane) {
-    constexpr int SLAB = LT * BKE * 2;
-    constexpr int NI = SLAB / 1024 / 8;
+    constexpr int SLAB = ROWS * BKE * 2;
+    constexpr int NI = SLAB / 1024 / 8;              // 1-KiB pieces per wave
+    static_assert(NI >= 1, "slab too small for 8 waves");
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int piece = wave * NI + i;
@@ -409,8 +409,10 @@ __device__ __forceinline__ void glds_slab(const bf16_t* __restrict__ base, long 
             gr = gr < lim ? gr : lim - 1;                // rows past the edge re-read the last row; never stored
             src = base + (long)gr * ld + k0 + c * 8;
         } else {
-            const int kr = piece * 2 + (lane >> 5);
-            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            constexpr int SPR = ROWS / 8;                // 16-B slots per k-row
+            constexpr int RPP = 64 / SPR;
+            const int kr = piece * RPP + lane / SPR;
+            const int c = (lane % SPR) ^ ((kr & 3) << 2);
             int gc = row0 + c * 8;
             gc = gc < lim ? gc : lim - 8;
             src = base + (long)(k0 + kr) * ld + gc;
@@ -420,7 +422,7 @@ __device__ __forceinline__ void glds_slab(const bf16_t* __restrict__ base, long 
     }
 }
 
-template <int BKE, bool TRANS>
+template <int BKE, bool TRANS, int ROWS>
 __device__ __forceinline__ u32x4 read_frag_l(const char* slab, int row32, int kk, int lane) {
     if (!TRANS) {
         const int r = row32 + (lane & 31);
@@ -430,10 +432,10 @@ __device__ __forceinline__ u32x4 read_frag_l(const char* slab, int row32, int kk
         const int a = lane & 15;
         const int mm = row32 + ((lane >> 4) & 1) * 16 + (a & 3) * 4;
         const int kr = kk * 16 + (lane >> 5) * 8 + (a >> 2);
-        const char* p = slab + kr * 512 + (((mm >> 3) ^ ((kr & 3) << 2)) << 4) + (mm & 7) * 2;
+        const char* p = slab + kr * (ROWS * 2) + (((mm >> 3) ^ ((kr & 3) << 2)) << 4) + (mm & 7) * 2;
         typedef s16x4 __attribute__((address_space(3))) * lptr;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * 512));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * (ROWS * 2)));
         union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
         u.s.lo = lo; u.s.hi = hi;
         return u.v;
@@ -442,38 +444,42 @@ __device__ __forceinline__ u32x4 read_frag_l(const char* slab, int row32, int kk
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename TO, bool TA, bool TB, int BKE, int NSTAGE>
-__global__ __launch_bounds__(LTHREADS) void gemm_large_kernel(GemmParams p) {
+// TM x TN block tile, 8 waves as WM_ x WN_, each wave (TM/WM_) x (TN/WN_) = FM x FN MFMA 32x32 blocks.
+template <typename TO, bool TA, bool TB, int BKE, int NSTAGE, int TM, int TN, int WM_, int WN_, int MINW>
+__global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int SLAB = LT * BKE * 2;              // bytes of one operand slab
-    constexpr int LPS = 2 * (SLAB / 1024 / 8);      // global_load_lds issued per wave per stage (A + B)
+    static_assert(WM_ * WN_ == 8, "8 waves");
+    constexpr int SLAB_A = TM * BKE * 2, SLAB_B = TN * BKE * 2, STAGE = SLAB_A + SLAB_B;
+    constexpr int LPS = SLAB_A / 1024 / 8 + SLAB_B / 1024 / 8;      // global_load_lds per wave per stage
     constexpr int KSTEPS = BKE / 16;
+    constexpr int FM = TM / WM_ / 32, FN = TN / WN_ / 32;
+    static_assert(FN == 2, "the epilogue stages 64-column blocks");
+    static_assert(NSTAGE * STAGE >= 8 * EP_WAVE_FLOATS * 4, "operand ring doubles as epilogue scratch");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int tiles_n = (p.N + LT - 1) / LT;
+    const int wm = wave / WN_, wn = wave % WN_;
+    const int tiles_n = (p.N + TN - 1) / TN;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (t / tiles_n) * LT, n0 = (t % tiles_n) * LT;
+    const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
     const int nk = p.K / BKE;
     const int kt0 = blockIdx.z * p.ksplit;
     const int kt1 = min(nk, kt0 + p.ksplit);
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
 
-    f32x16 acc[4][2];
+    f32x16 acc[FM][FN];
     {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = zero;
+            for (int j = 0; j < FN; ++j) acc[i][j] = zero;
     }
-
     // prologue: fill NSTAGE-1 stages
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
         if (kt0 + s < kt1) {
-            glds_slab<BKE, TA>(A, p.lda, m0, p.M, (kt0 + s) * BKE, lds + (2 * s) * SLAB, wave, lane);
-            glds_slab<BKE, TB>(B, p.ldb, n0, p.N, (kt0 + s) * BKE, lds + (2 * s + 1) * SLAB, wave, lane);
+            glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, (kt0 + s) * BKE, lds + s * STAGE, wave, lane);
+            glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, (kt0 + s) * BKE, lds + s * STAGE + SLAB_A, wave, lane);
         }
     }
     int stage = 0;
@@ -488,22 +494,22 @@ __global__ __launch_bounds__(LTHREADS) void gemm_large_kernel(GemmParams p) {
         const int nxt = kt + NSTAGE - 1;
         if (nxt < kt1) {
             int ns = stage + NSTAGE - 1; ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-            glds_slab<BKE, TA>(A, p.lda, m0, p.M, nxt * BKE, lds + (2 * ns) * SLAB, wave, lane);
-            glds_slab<BKE, TB>(B, p.ldb, n0, p.N, nxt * BKE, lds + (2 * ns + 1) * SLAB, wave, lane);
+            glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, nxt * BKE, lds + ns * STAGE, wave, lane);
+            glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, nxt * BKE, lds + ns * STAGE + SLAB_A, wave, lane);
         }
-        const char* sa = lds + (2 * stage) * SLAB;
-        const char* sb = sa + SLAB;
+        const char* sa = lds + stage * STAGE;
+        const char* sb = sa + SLAB_A;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            u32x4 fa[4], fb[2];
+            u32x4 fa[FM], fb[FN];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag_l<BKE, TB>(sb, wn * 64 + j * 32, kk, lane);
+            for (int j = 0; j < FN; ++j) fb[j] = read_frag_l<BKE, TB, TN>(sb, wn * (FN * 32) + j * 32, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag_l<BKE, TA>(sa, wm * 128 + i * 32, kk, lane);
+            for (int i = 0; i < FM; ++i) fa[i] = read_frag_l<BKE, TA, TM>(sa, wm * (FM * 32) + i * 32, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma<bf16_t>(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < FN; ++j) mma<bf16_t>(acc[i][j], fa[i], fb[j]);
         }
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
@@ -511,23 +517,22 @@ __global__ __launch_bounds__(LTHREADS) void gemm_large_kernel(GemmParams p) {
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     __builtin_amdgcn_s_barrier();                       // every wave is done with the operand ring: reuse it as scratch
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
-    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 128, n0 + wn * 64, lane, atomic, vec_ok);
-    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 128 + 32, n0 + wn * 64, lane, atomic, vec_ok);
-    epilogue_block<TO>(p, acc[2][0], acc[2][1], wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane, atomic, vec_ok);
-    epilogue_block<TO>(p, acc[3][0], acc[3][1], wlds, m0 + wm * 128 + 96, n0 + wn * 64, lane, atomic, vec_ok);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+        epilogue_block<TO>(p, acc[i][0], acc[i][1], wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok);
 }
 
-template <typename TO, bool TA, bool TB, int BKE, int NSTAGE>
+template <typename TO, bool TA, bool TB, int BKE, int NSTAGE, int TM, int TN, int WM_, int WN_, int MINW>
 int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
-    constexpr int SMEM = NSTAGE * 2 * LT * BKE * 2;
+    constexpr int SMEM = NSTAGE * (TM + TN) * BKE * 2;
     static bool configured = false;
-    auto kern = gemm_large_kernel<TO, TA, TB, BKE, NSTAGE>;
+    auto kern = gemm_large_kernel<TO, TA, TB, BKE, NSTAGE, TM, TN, WM_, WN_, MINW>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
         configured = true;
     }
-    const int tiles = ((p.M + LT - 1) / LT) * ((p.N + LT - 1) / LT);
+    const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
     const int nk = p.K / BKE;
     GemmParams q = p;
     if (splitk < 1) splitk = 1;
@@ -539,7 +544,8 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
-// variant: 0 = auto, 1 = force the 128x128 kernel, 2 = 256x256 BK64 x2 stages, 3 = 256x256 BK32 x4 stages
+// variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 BK64 x2 stages, 3 = 256x256 BK32 x4-stage ring,
+//          4 = 256x128 BK32 x3-stage ring at 2 blocks/CU
 int g_gemm_variant = 0;
 
 template <typename TO, bool TA, bool TB>
@@ -552,8 +558,9 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // over >= 48 slabs (K >= 3072); split-K wgrad and K = 768 are faster on the 128x128 kernel (3 blocks/CU overlap)
     if (v == 0) v = (big_ok && !TA && kper >= 48) ? 2 : 1;
     if (!big_ok) v = 1;
-    if (v == 2) return launch_large<TO, TA, TB, 64, 2>(p, splitk, s);
-    if (v == 3) return launch_large<TO, TA, TB, 32, 4>(p, splitk, s);
+    if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
+    if (v == 3) return launch_large<TO, TA, TB, 32, 4, 256, 256, 2, 4, 2>(p, splitk, s);
+    if (v == 4) return launch_large<TO, TA, TB, 32, 3, 256, 128, 4, 2, 4>(p, splitk, s);
     return launch<bf16_t, TO, TA, TB>(p, splitk, s);
 }
 
