@@ -96,6 +96,50 @@ def cpu_baseline(img, L, budget_s=20.0):
             "sample": f"{n} fwd+bwd+AdamW steps of {B} pairs (ViT-B/16 @{img}, BERT-base L={L}) with the torch-fp32 oracle"}
 
 
+def seg_eval_bench(dev, world, dtype, windows=16, steps=4, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
+    """Zero-shot segmentation GPU stage (BASELINE configs[3] shape): ViT-B on 512x512 windows -> projection -> LoDA pooled
+    embedding + dense patch x class-text similarity map for all `classes` (tools/seg_evaluation.py:99-143 without the CPU
+    CRF stage).  Independent windows: sharded over ranks with no collective.  Returns windows/s over all ranks."""
+    from simseg_amd.heads import patch_text_similarity
+    from simseg_amd import ops
+    from simseg.models import PIPELINE
+    os.environ["SIMSEG_AMD_COMPUTE"] = dtype
+    cfg, build = build_model(tag, dim, img)
+    torch.manual_seed(7)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(classes, 512, generator=g), dim=-1).to(dev)
+    images = torch.randn(windows, 3, img, img, generator=g).to(dev)
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+
+    def step():
+        with torch.no_grad():
+            feats = model.forward_image_feature(images)                 # [B, 1024, 768]
+            pooled = model.forward_image_project(feats)                 # [B, 512]
+            tok = model.image_projection(feats)                         # [B, 1024, 512]
+            sim = patch_text_similarity(tok, text, compute_dtype=cdt)   # [B, 1024, classes]
+            scores = ops.gemm(pooled, text)                             # [B, classes]
+        return sim, scores
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    del model
+    n_patches = (img // 16) ** 2
+    t = n_patches + 1
+    fl = 12 * (24 * t * dim * dim + 4 * t * t * dim) + 2 * n_patches * 768 * dim + 2 * 2 * n_patches * dim * 512 + 2 * n_patches * 512 * classes
+    wps = world * windows * steps / float(el)
+    return {"windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
+            "classes": classes, "windows_per_step_per_gpu": windows, "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
+            "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +150,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--tag", default="vit_base_patch16_224_in21k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seg", action="store_true", help="skip the zero-shot-seg eval stage measurement")
     args = ap.parse_args()
 
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
@@ -142,7 +187,7 @@ def main():
     log("model and batch on device")
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=(world == 1))     # under DDP the grads are views into the all-reduce buckets
         loss_dict, _, _ = net(batch)
         loss_dict["nce_loss"].backward()
         opt.step()
@@ -177,6 +222,13 @@ def main():
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
     ops.PROFILE = None
+    del net, model, opt, batch
+    torch.cuda.empty_cache()
+    seg = None
+    if not args.no_seg:
+        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16")}
+        os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+        log(f"seg eval stage: {seg}")
 
     if rank == 0:
         n_patches = (args.img // 16) ** 2
@@ -207,6 +259,7 @@ def main():
                            "gemm_time_share": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4)},
+            "seg_eval": seg,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

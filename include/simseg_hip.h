@@ -26,6 +26,7 @@ const char* simseg_last_error(void);
  * act (1 = erf-GELU, 2 = multiply by GELU'(aux)), dropout(p, seed), +residual.  row_group=G>0 writes row r to
  * (r/G)*(G+1)+1+r%G (ViT patch rows behind [cls]); res_mod reads the residual at row 1+r%G (pos_embed).
  * splitk>1 accumulates fp32 partials atomically into C (C must hold the value to accumulate onto).
+ * colsum (optional, [N]) += column sums of the stored output: the bias gradient of the layer that produced C's input.
  * Replaces: nn.Linear inside timm Block / HF BertLayer (called via simseg/models/backbones/mml/vit_builder.py:18,
  * huggingface_builder.py:16-17), Conv2d patch embed (vit_builder.py:14), SimpleProjection
  * (simseg/models/components/projection.py:45-46), the logits matmul (simseg/models/criteria/losses/mml_loss.py:73),
@@ -33,7 +34,8 @@ const char* simseg_last_error(void);
 int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldc, int in_dtype, int out_dtype, int transA, int transB, float alpha, const float* bias,
                 const float* rowscale, const float* residual, int64_t ldr, int act, const void* aux, void* aux_out,
-                int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, void* stream);
+                int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, float* colsum,
+                void* stream);
 
 /* Kernel selection for benchmarking: 0 auto, 1 128x128 register-staged, 2 256x256 BK64x2, 3 256x256 BK32x4 ring. */
 int simseg_set_gemm_variant(int v);
@@ -43,10 +45,12 @@ int simseg_set_gemm_variant(int v);
  * (eps 1e-6) and HF Bert*Output.LayerNorm / BertEmbeddings.LayerNorm (eps 1e-12). */
 int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_dtype, void* y_bf16,
                          float* mean, float* rstd, int64_t rows, int64_t D, float eps, void* stream);
-/* dx = LN'(dy_bf16 + dy_f32) + dres; writes dx_f32 and/or dx_bf16; dgamma/dbeta are ACCUMULATED. */
+/* dx = LN'(dy_bf16 + dy_f32) + dres; writes dx_f32 and/or dx_bf16 (the bf16 copy optionally with the dropout mask
+ * (drop_seed, drop_p) of the producing dense layer re-applied); dgamma/dbeta and dxsum (column sums of dx_bf16's values,
+ * optional) are ACCUMULATED. */
 int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x, const float* mean,
                          const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
-                         float* dbeta, int64_t rows, int64_t D, void* stream);
+                         float* dbeta, float* dxsum, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p, void* stream);
 
 /* out[n] += sum_r in[r,n]  (bias / embedding-table gradients). */
 int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream);

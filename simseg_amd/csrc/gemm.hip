@@ -47,6 +47,7 @@ struct GemmParams {
     int ksplit;              // k-tiles per z-slice
     // dropout on (acc*alpha + bias), before the residual:  keep iff hash(seed, row*N+col) >= thresh
     unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
+    float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the producing layer)
 };
 
 template <typename T> struct TT;
@@ -174,7 +175,7 @@ template <> struct Vec8<bf16_t> {
 // Emits rows [row0, row0+32) x cols [col0, col0+64) from two 32x32 accumulators (left/right 32 columns).
 template <typename TO>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16& accL, const f32x16& accR, float* wlds, int row0,
-                                               int col0, int lane, bool atomic, bool vec_ok) {
+                                               int col0, int lane, bool atomic, bool vec_ok, float (&cs)[8]) {
     const int h2 = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -260,6 +261,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
                 }
             }
             Vec8<TO>::store(C + o, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += v[e];
         } else {
             for (int e = 0; e < 8 && col + e < p.N; ++e) {
                 float x = v[e] * rs + (p.bias ? p.bias[col + e] : 0.f);
@@ -275,11 +278,29 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
                     if (p.accumulate) x += ld_out(C + o + e);
                 }
                 st_out(C + o + e, x);
+                if (p.colsum) atomicAdd(p.colsum + col + e, x);
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// lanes with equal lane%8 hold partial sums of the same 8 columns: fold the 8 row groups, then 8 lanes x 8 atomics
+__device__ __forceinline__ void flush_colsum(const GemmParams& p, float (&cs)[8], int col0, int lane) {
+    if (!p.colsum) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        cs[e] = v;
+    }
+    if (lane < 8) {
+        const int col = col0 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < p.N) atomicAdd(p.colsum + col + e, cs[e]);
+    }
 }
 
 // 16-byte vector accesses need aligned bases and leading dimensions
@@ -353,8 +374,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
     const bool atomic = gridDim.z > 1;
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
-    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 64, n0 + wn * 64, lane, atomic, vec_ok);
-    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 64 + 32, n0 + wn * 64, lane, atomic, vec_ok);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 64, n0 + wn * 64, lane, atomic, vec_ok, cs);
+    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 64 + 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+    flush_colsum(p, cs, n0 + wn * 64, lane);
 }
 
 template <typename T, typename TO, bool TA, bool TB, bool AL = true>
@@ -517,9 +540,11 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     __builtin_amdgcn_s_barrier();                       // every wave is done with the operand ring: reuse it as scratch
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < FM; ++i)
-        epilogue_block<TO>(p, acc[i][0], acc[i][1], wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok);
+        epilogue_block<TO>(p, acc[i][0], acc[i][1], wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+    flush_colsum(p, cs, n0 + wn * 64, lane);
 }
 
 template <typename TO, bool TA, bool TB, int BKE, int NSTAGE, int TM, int TN, int WM_, int WN_, int MINW>
@@ -579,7 +604,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
                            int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int transA, int transB, float alpha,
                            const float* bias, const float* rowscale, const float* residual, int64_t ldr, int act,
                            const void* aux, void* aux_out, int row_group, int res_mod, int accumulate, int splitk,
-                           uint64_t drop_seed, float drop_p, void* stream) {
+                           uint64_t drop_seed, float drop_p, float* colsum, void* stream) {
     SS_CHECK(A && B && C, "simseg_gemm: null operand");
     SS_CHECK(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "simseg_gemm: bad shape %lld x %lld x %lld",
              (long long)M, (long long)N, (long long)K);
@@ -594,7 +619,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
                          (transA ? M : K) % epc == 0 && (transB ? N : K) % epc == 0;
     SS_CHECK(aligned || in_dtype == 0, "simseg_gemm: bf16 operands need 16-byte aligned pointers and contiguous extents / leading dimensions that are multiples of 8");
     SS_CHECK(((uintptr_t)A % 4) == 0 && ((uintptr_t)B % 4) == 0, "simseg_gemm: misaligned operand");
-    SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f),
+    SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f && !colsum),
              "simseg_gemm: split-K needs a plain fp32 accumulate epilogue");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "simseg_gemm: dropout p out of range");
     SS_CHECK(act != 2 || aux, "simseg_gemm: act=2 needs aux");
@@ -606,6 +631,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.residual = residual; p.ldr = ldr; p.act = act; p.aux = aux; p.aux_out = aux_out;
     p.row_group = row_group; p.res_mod = res_mod; p.accumulate = accumulate;
     p.drop_seed = drop_seed;
+    p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     hipStream_t s = (hipStream_t)stream;

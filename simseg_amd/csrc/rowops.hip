@@ -80,31 +80,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // LayerNorm backward.  dy = dy16 (bf16, optional) + dy32 (fp32, optional);  dx = ln_bwd(dy) + dres (optional)
-// Writes dx32 (fp32 residual-gradient stream) and dx16 (bf16 copy fed to the next dgrad/wgrad GEMMs);
-// dgamma/dbeta are accumulated with one atomic per column per block.
+// Writes dx32 (fp32 residual-gradient stream) and dx16 (bf16 copy fed to the next dgrad/wgrad GEMMs, optionally with
+// the forward dropout mask of the producing dense layer re-applied); dgamma/dbeta and the column sums of dx16 (= the
+// bias gradient of that dense layer) are accumulated with one atomic per column per block.
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
                                                      const float* __restrict__ dres, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx32,
                                                      bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int D) {
-    __shared__ float red[2][1024];   // [dgamma|dbeta][wave * 256 + lane * 4 + j]
+                                                     float* __restrict__ dbeta, float* __restrict__ dxsum, int rows, int D,
+                                                     unsigned long long drop_seed, unsigned int drop_thresh, float drop_scale) {
+    __shared__ float red[3][1024];   // [dgamma|dbeta|dxsum][wave * 256 + lane * 4 + j]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    float ag[LN_MAXC][4], ab[LN_MAXC][4], gm[LN_MAXC][4];
+    float ag[MAXC][4], ab[MAXC][4], as[MAXC][4], gm[MAXC][4];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; gm[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; gm[i][j] = 0.f; }
         const int c = lane + 64 * i;
         if (c < nch) load4<float>(gamma + c * 4, gm[i]);
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float g[LN_MAXC][4], xh[LN_MAXC][4];
+        float g[MAXC][4], xh[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 const long o = (long)row * D + c * 4;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         s1 = wave_sum(s1) / D;
         s2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 const long o = (long)row * D + c * 4;
@@ -135,29 +138,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + r[j];
                 if (dx32) store4<float>(dx32 + o, out);
+                if (drop_thresh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) out[j] = dropout_keep(drop_seed, (unsigned long long)o + j, drop_thresh) ? out[j] * drop_scale : 0.f;
+                }
                 if (dx16) store4<bf16_t>(dx16 + o, out);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) as[i][j] += out[j];
             }
         }
     }
     // cross-wave reduction of the column partials, then one atomic per column per block
-    float* rg = red[0];
-    float* rb = red[1];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         __syncthreads();
         if (c < nch) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { rg[wave * 256 + lane * 4 + j] = ag[i][j]; rb[wave * 256 + lane * 4 + j] = ab[i][j]; }
+            for (int j = 0; j < 4; ++j) {
+                red[0][wave * 256 + lane * 4 + j] = ag[i][j];
+                red[1][wave * 256 + lane * 4 + j] = ab[i][j];
+                red[2][wave * 256 + lane * 4 + j] = as[i][j];
+            }
         }
         __syncthreads();
         if (wave == 0 && c < nch) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float sg = 0.f, sb = 0.f;
-                for (int w = 0; w < 4; ++w) { sg += rg[w * 256 + lane * 4 + j]; sb += rb[w * 256 + lane * 4 + j]; }
+                float sg = 0.f, sb = 0.f, ss = 0.f;
+                for (int w = 0; w < 4; ++w) { sg += red[0][w * 256 + lane * 4 + j]; sb += red[1][w * 256 + lane * 4 + j]; ss += red[2][w * 256 + lane * 4 + j]; }
                 atomicAdd(dgamma + c * 4 + j, sg);
                 atomicAdd(dbeta + c * 4 + j, sb);
+                if (dxsum) atomicAdd(dxsum + c * 4 + j, ss);
             }
         }
     }
@@ -426,13 +438,25 @@ extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const fl
 
 extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x,
                                     const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
-                                    float* dgamma, float* dbeta, int64_t rows, int64_t D, void* stream) {
+                                    float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t D, uint64_t drop_seed,
+                                    float drop_p, void* stream) {
     SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
+    SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
     if (rows <= 0) return 0;
     const int grid = grid_for(rows, 4, 1024);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, x, mean, rstd, gamma,
-                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, (int)rows, (int)D);
+    const unsigned int thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int nc = (int)((D + 255) / 256);
+#define LN_BWD_LAUNCH(C)                                                                                                              \
+    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, x, mean, rstd, gamma, \
+                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
+    if (nc <= 1) LN_BWD_LAUNCH(1);
+    else if (nc == 2) LN_BWD_LAUNCH(2);
+    else if (nc == 3) LN_BWD_LAUNCH(3);
+    else if (nc == 4) LN_BWD_LAUNCH(4);
+    else LN_BWD_LAUNCH(8);
+#undef LN_BWD_LAUNCH
     SS_LAUNCH_CHECK("layernorm_bwd");
     return 0;
 }

@@ -31,7 +31,7 @@ PROFILE = None   # bench.py sets this to a list to time every GEMM launch with e
 
 def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=1.0, bias=None, rowscale=None,
          residual=None, act=0, aux=None, aux_out=None, row_group=0, res_mod=False, accumulate=False, splitk=1,
-         drop_seed=0, drop_p=0.0, out_rows=None):
+         drop_seed=0, drop_p=0.0, out_rows=None, colsum=None):
     """C = epilogue(alpha * op(a) @ op(b)); a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b)."""
     require_gpu(a, b)
     _c(a); _c(b)
@@ -51,7 +51,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
     call("simseg_gemm", ptr(a), ptr(b), ptr(out), M, N, K, a.shape[1], b.shape[1], out.shape[-1], dt(a), dt(out),
          int(trans_a), int(trans_b), float(alpha), ptr(_c(bias)), ptr(_c(rowscale)), ptr(_c(residual)), ldr, int(act),
          ptr(_c(aux)), ptr(_c(aux_out)), int(row_group), int(res_mod), int(accumulate), int(splitk), int(drop_seed),
-         float(drop_p), stream())
+         float(drop_p), ptr(colsum), stream())
     if PROFILE is not None:
         e1.record()
         kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
@@ -72,14 +72,15 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, want_bf16_copy=F
     return y, y16, mean, rstd
 
 
-def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dres=None, want_f32=True, want_bf16=True):
+def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dres=None, want_f32=True, want_bf16=True,
+                  dxsum=None, drop_seed=0, drop_p=0.0):
     require_gpu(x)
     D = x.shape[-1]
     rows = x.numel() // D
     dx32 = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_f32 else None
     dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
     call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
-         ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), rows, D, stream())
+         ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), rows, D, int(drop_seed), float(drop_p), stream())
     return dx32, dx16
 
 

@@ -41,6 +41,20 @@ def _bgrad(dy16):
     return db
 
 
+# bf16 copy + column sums of a gradient tensor handed from one block's backward to the next (saves a cast pass and a
+# column-sum pass per block).  Keyed by the fp32 tensor's storage address; consumed (popped) by the receiver.
+_SHADOW = {}
+
+
+def _put_shadow(t32, t16, colsum):
+    _SHADOW.clear()
+    _SHADOW[(t32.data_ptr(), tuple(t32.shape))] = (t16, colsum)
+
+
+def _take_shadow(t32):
+    return _SHADOW.pop((t32.data_ptr(), tuple(t32.shape)), None)
+
+
 def _need_bf16(adt, what):
     if adt != BF16:
         raise RuntimeError(f"{what}: the backward pass runs in bf16 compute mode only (enable torch.autocast or set "
@@ -86,8 +100,9 @@ class LayerNormFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, w = ctx.saved_tensors
-        dg, db = torch.zeros_like(w), torch.zeros_like(w)
-        dx, _ = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), want_bf16=False)
+        dg, db, dsum = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+        dx, dx16 = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), dxsum=dsum)
+        _put_shadow(dx, dx16, dsum)
         return dx, dg, db, None
 
 
@@ -163,32 +178,39 @@ class ViTBlockFn(Function):
         x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_, n1w, n2w = ctx.saved_tensors
         B, T, D = ctx.dims
         need = ctx.needs_input_grad
-        dy = dy.contiguous().view(-1, D)
-        dy16 = ops.cast(dy, BF16)
+        dy = dy.contiguous()
+        sh = _take_shadow(dy)
+        dy = dy.view(-1, D)
+        if sh is not None:
+            dy16, df2b = sh[0].view(-1, D), sh[1]
+        else:
+            dy16 = ops.cast(dy, BF16)
+            df2b = _bgrad(dy16) if need[14] else None
         # mlp
-        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=2, aux=pre)
+        df1b = torch.zeros(4 * D, device=dy.device, dtype=F32)
+        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=2, aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act) if need[13] else None
-        df2b = _bgrad(dy16) if need[14] else None
         dln2 = ops.gemm(dpre, f1w_, trans_b=True)
         df1w = _wgrad(dpre, ln2) if need[11] else None
-        df1b = _bgrad(dpre) if need[12] else None
-        dn2w, dn2b = torch.zeros_like(n2w), torch.zeros_like(n2w)
-        dx1_32, dx1_16 = ops.layernorm_bwd(x1, mean2, rstd2, n2w, dn2w, dn2b, dy16=dln2, dres=dy)
+        dn2w, dn2b, dpb = torch.zeros_like(n2w), torch.zeros_like(n2w), torch.zeros_like(n2w)
+        dx1_32, dx1_16 = ops.layernorm_bwd(x1, mean2, rstd2, n2w, dn2w, dn2b, dy16=dln2, dres=dy, dxsum=dpb)
         # attention
         datt = ops.gemm(dx1_16, pw_, trans_b=True)
         dpw = _wgrad(dx1_16, att.view(-1, D)) if need[7] else None
-        dpb = _bgrad(dx1_16) if need[8] else None
         dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5).view(-1, 3 * D)
         dln1 = ops.gemm(dqkv, qw_, trans_b=True)
         dqw = _wgrad(dqkv, ln1.view(-1, D)) if need[5] else None
         dqb = _bgrad(dqkv) if need[6] else None
-        dn1w, dn1b = torch.zeros_like(n1w), torch.zeros_like(n1w)
-        dx, _ = ops.layernorm_bwd(x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dy16=dln1, dres=dx1_32, want_bf16=False)
-        return (dx.view(B, T, D), None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
+        dn1w, dn1b, dsum = torch.zeros_like(n1w), torch.zeros_like(n1w), torch.zeros_like(n1w)
+        dx, dx16 = ops.layernorm_bwd(x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dy16=dln1, dres=dx1_32, dxsum=dsum)
+        dx = dx.view(B, T, D)
+        _put_shadow(dx, dx16, dsum)
+        return (dx, None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
 
 
 def vit_forward(m, image, adt):
     """m: module tree with timm parameter names (see simseg_amd/nn.py ViT). Returns all tokens after the final LN."""
+    _SHADOW.clear()
     x = ViTEmbedFn.apply(image, m.patch_embed.proj.weight, m.patch_embed.proj.bias, m.cls_token, m.pos_embed, adt)
     for blk in m.blocks:
         x = ViTBlockFn.apply(x, m.num_heads, adt, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
@@ -281,23 +303,17 @@ class BertLayerFn(Function):
         p, seed = ctx.drop
         need = ctx.needs_input_grad
         dy = dy.contiguous().view(-1, D)
-        dlow, dlob = torch.zeros_like(low), torch.zeros_like(low)
-        ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy)
-        if p > 0:
-            ops.dropout_apply_(d2, seed + 2, p)
-        dpre = ops.gemm(d2, o2w_, trans_b=True, act=2, aux=pre)
+        dlow, dlob, do2b = torch.zeros_like(low), torch.zeros_like(low), torch.zeros_like(low)
+        ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy, dxsum=do2b, drop_seed=seed + 2, drop_p=p)
+        dib = torch.zeros(pre.shape[1], device=dy.device, dtype=F32)
+        dpre = ops.gemm(d2, o2w_, trans_b=True, act=2, aux=pre, colsum=dib)
         do2w = _wgrad(d2, act) if need[18] else None
-        do2b = _bgrad(d2) if need[19] else None
         da = ops.gemm(dpre, iw_, trans_b=True)
         diw = _wgrad(dpre, aa) if need[16] else None
-        dib = _bgrad(dpre) if need[17] else None
-        dlaw, dlab = torch.zeros_like(law), torch.zeros_like(law)
-        ds1_32, d1 = ops.layernorm_bwd(s1, mean_a, rstd_a, law, dlaw, dlab, dy16=da, dy32=ds2_32)
-        if p > 0:
-            ops.dropout_apply_(d1, seed + 1, p)
+        dlaw, dlab, dob = torch.zeros_like(law), torch.zeros_like(law), torch.zeros_like(law)
+        ds1_32, d1 = ops.layernorm_bwd(s1, mean_a, rstd_a, law, dlaw, dlab, dy16=da, dy32=ds2_32, dxsum=dob, drop_seed=seed + 1, drop_p=p)
         datt = ops.gemm(d1, ow_, trans_b=True)
         dow = _wgrad(d1, att.view(-1, D)) if need[12] else None
-        dob = _bgrad(d1) if need[13] else None
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), att, datt.view(B, L, D), lse, ctx.heads, mask, scale=64 ** -0.5,
                                  drop_seed=seed, drop_p=p).view(-1, 3 * D)
         dx = ops.gemm(dqkv, wqkv, trans_b=True, residual=ds1_32, out_dtype=F32)

@@ -69,6 +69,12 @@ def test_gemm_f32_epilogues(ops):
     acc = _rand(M, N, seed=7)
     want = acc + a @ b.T
     _close(ops.gemm(a, b, out=acc, accumulate=True), want, 1e-5, "accumulate")
+    cs = torch.ones(N, device="cuda")
+    y = ops.gemm(a, b, bias=bias, colsum=cs)
+    _close(cs, 1 + y.sum(0), 1e-5, "epilogue column sums")
+    cs = torch.zeros(N, device="cuda")
+    y16 = ops.gemm(a.bfloat16(), b.bfloat16(), bias=bias, colsum=cs)
+    _close(cs, (a.bfloat16().float() @ b.bfloat16().float().T + bias).sum(0), 1e-4, "epilogue column sums (bf16, pre-rounding values)")
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
@@ -156,6 +162,15 @@ def test_layernorm_fwd_bwd(ops, D):
     _close(dx16, xr.grad + dres, 1e-2, "ln bwd dx bf16")
     _close(dgam, gr.grad, 1e-4, "ln bwd dgamma")
     _close(dbet, br.grad, 1e-4, "ln bwd dbeta")
+    # fused extras: column sums of the bf16 output and re-application of a dense layer's dropout mask to it
+    dgam.zero_(); dbet.zero_()
+    dsum = torch.zeros(D, device="cuda")
+    dx32b, dx16b = ops.layernorm_bwd(x, mean, rstd, g, dgam, dbet, dy16=dy16, dy32=dy32, dres=dres, dxsum=dsum, drop_seed=77, drop_p=0.1)
+    assert torch.equal(dx32b, dx32)                      # the fp32 stream is never masked
+    keep = torch.ones(rows, D, device="cuda")
+    ops.dropout_apply_(keep, 77, 0.1)
+    _close(dx16b, dx32 * keep, 1e-2, "ln bwd masked bf16 output")
+    _close(dsum, (dx32 * keep).sum(0), 1e-4, "ln bwd column sums")
 
 
 def test_colsum_transpose_cast(ops):

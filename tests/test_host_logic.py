@@ -79,7 +79,7 @@ def test_c_abi_exports_every_declared_symbol():
     l = lib.load()
     assert l.simseg_version() >= 100
     # argument validation happens before any device work: callable without a GPU
-    assert l.simseg_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, 0, 0, None, None, 0, 0, 0, 1, 0, 0.0, None) != 0
+    assert l.simseg_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, 0, 0, None, None, 0, 0, 0, 1, 0, 0.0, None, None) != 0
     assert b"null operand" in l.simseg_last_error()
 
 
