@@ -61,7 +61,7 @@ __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias,
 // ------------------------------------------------------------------------------------------------
 constexpr int KP32 = 272, VP32 = 256;
 
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(512) void attn_fwd_f32_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP32 + KT * VP32 + KT * 4];
     char* ldsK = lds;
     char* ldsV = lds + KT * KP32;
@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
     const int T = p.T;
     const long RS = 3L * p.H * 64;
     const float* base = static_cast<const float*>(p.qkv) + (long)b * T * RS + h * 64;
-    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    const int nthr = blockDim.x;
+    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
 
     float qr[8][4];
 #pragma unroll
@@ -89,9 +90,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
 
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {      // 64 keys x 16 chunks of 16 B, for K and V
-            const int idx = tid + 256 * i;
+        for (int idx = tid; idx < KT * 16; idx += nthr) {      // 64 keys x 16 chunks of 16 B, for K and V
             const int key = idx >> 4, c = idx & 15;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (kv0 + key < T) {
@@ -113,6 +112,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            if (kv0 + kb * 32 >= T) continue;       // whole 32-key block is padding (kbias = NEG makes its P exactly 0)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float4 a = *reinterpret_cast<const float4*>(ldsK + (kb * 32 + ql) * KP32 + (8 * c + 4 * h2) * 4);
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kv0 + kb * 32 >= T) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[kb][r], o[db], 0, 0, 0);
                 }
             }
+        }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
@@ -175,7 +177,7 @@ __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) {
     return u.h;
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * VP16 + KT * 4];
     char* ldsK = lds;
     char* ldsV = lds + KT * KP16;
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
     const int T = p.T;
     const long RS = 3L * p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
-    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    const int nthr = blockDim.x;
+    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
 
     bf16x8 qr[4];
 #pragma unroll
@@ -205,9 +208,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
 
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {      // 64 keys x 8 chunks of 16 B, for K and V
-            const int idx = tid + 256 * i;
+        for (int idx = tid; idx < KT * 8; idx += nthr) {      // 64 keys x 8 chunks of 16 B, for K and V
             const int key = idx >> 3, c = idx & 7;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
             if (kv0 + key < T) {
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            if (kv0 + kb * 32 >= T) continue;       // whole 32-key block is padding (kbias = NEG makes its P exactly 0)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 a = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
                 }
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kv0 + kb * 32 >= T) continue;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf;
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                 }
             }
+        }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
 constexpr int QP = 144;  // pitch of the Q / dO tiles (read both k-contiguous and transposed)
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * QT * QP + 2 * QT * 4];
     char* ldsQ = lds;
     char* ldsG = lds + QT * QP;                         // dO tile
@@ -324,7 +328,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
-    const int key = blockIdx.x * 128 + wave * 32 + kl;
+    const int nthr = blockDim.x;
+    const int key = blockIdx.x * (nthr >> 1) + wave * 32 + kl;
     const bool kvalid = key < T;
     const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
 
@@ -349,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 
     for (int q0 = 0; q0 < T; q0 += QT) {
         __syncthreads();
-        {   // 32 queries x 8 chunks = 256 chunks each for Q and dO
-            const int qq = tid >> 3, c = tid & 7;
+        for (int idx = tid; idx < QT * 8; idx += nthr) {   // 32 queries x 8 chunks = 256 chunks each for Q and dO
+            const int qq = idx >> 3, c = idx & 7;
             u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
             if (q0 + qq < T) {
                 qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c * 8);
@@ -358,11 +363,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
             }
             *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = qv;
             *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = gv;
-            if (tid < QT) {
-                const bool v = q0 + tid < T;
-                lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + q0 + tid] : 1e30f;   // -> P = 0 for padded queries
-                delq[tid] = v ? p.delta[((long)b * p.H + h) * T + q0 + tid] : 0.f;
-            }
+        }
+        if (tid < QT) {
+            const bool v = q0 + tid < T;
+            lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + q0 + tid] : 1e30f;   // -> P = 0 for padded queries
+            delq[tid] = v ? p.delta[((long)b * p.H + h) * T + q0 + tid] : 0.f;
         }
         __syncthreads();
         // S[q][key], dP[q][key]: MFMA rows = queries (A from LDS), columns = keys (B = this lane's K / V row)
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int krow = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const int krow = blockIdx.x * (nthr >> 1) + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
             if (krow < T) {
                 dbase[(long)krow * RS + p.H * 64 + db * 32 + kl] = (bf16_t)dk[db][r];
                 dbase[(long)krow * RS + 2 * p.H * 64 + db * 32 + kl] = (bf16_t)dv[db][r];
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * KP16 + KT * 4];
     char* ldsK = lds;
     char* ldsV = lds + KT * KP16;
@@ -431,7 +436,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
-    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    const int nthr = blockDim.x;
+    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
     const bool qvalid = q < T;
 
     bf16x8 qr[4], gr[4];
@@ -457,9 +463,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
+        for (int idx = tid; idx < KT * 8; idx += nthr) {
             const int key = idx >> 3, c = idx & 7;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
             if (kv0 + key < T) {
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         __syncthreads();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kv0 + kb * 32 >= T) continue;
             // S^T[key][q], dP^T[key][q]: rows = keys (A from LDS), columns = queries (B = this lane's Q / dO row)
             f32x16 s, dp;
 #pragma unroll
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qrow = blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const int qrow = blockIdx.x * (nthr >> 1) + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
             if (qrow < T) dbase[(long)qrow * RS + db * 32 + ql] = (bf16_t)dq[db][r];
         }
 }
@@ -552,11 +557,14 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     SS_CHECK(out, "attention_fwd: null out");
     SS_CHECK(dtype == 1 || drop_p == 0.f, "attention_fwd: dropout is a training (bf16) feature");
     p.out = out; p.lse = lse;
-    dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H));
+    // one wave per 32 queries; a block holds up to 8 waves of the same (batch, head) so K/V tiles are staged once
+    const int q32 = (int)((T + 31) / 32);
+    const int nw = q32 < 8 ? q32 : ((q32 % 7 == 0 || q32 % 7 > q32 % 8) && q32 % 8 != 0 ? 7 : 8);
+    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
     if (dtype == 0)
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
@@ -573,9 +581,11 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     const long groups = B * T * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                        (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
-    dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, p);
+    const int q32 = (int)((T + 31) / 32);
+    const int nw = q32 < 8 ? q32 : ((q32 % 7 == 0 || q32 % 7 > q32 % 8) && q32 % 8 != 0 ? 7 : 8);
+    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(nw * 64), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(nw * 64), 0, s, p);
     SS_LAUNCH_CHECK("attention_bwd");
     return 0;
 }
