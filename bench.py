@@ -239,6 +239,13 @@ def main():
         cnt, fl, sec = agg[dom]
         achieved = fl / sec / 1e12
         gemm_sec = sum(a[2] for a in agg.values())
+        traffic = None          # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this command
+        try:
+            with open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")) as f:
+                traffic = json.load(f)["per_kind"].get(dom, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError, KeyError):
+            pass
+        kdesc = {"_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)", "": "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)"}["_L" if dom.endswith("_L") else ""]
         out = {
             "metric": "image-text pairs/sec (train)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -248,9 +255,9 @@ def main():
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel<{dom}> (32x32x16 bf16 MFMA, 128x128 tile)",
+            "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                          "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
                          "flops_per_launch_avg": fl / cnt},
             "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),

@@ -44,7 +44,8 @@ struct GemmParams {
     int row_group;           // >0: output row r -> (r / G) * (G + 1) + 1 + r % G  (ViT token rows after [cls])
     int res_mod;             // residual row = 1 + r % G (pos_embed) instead of the output row
     int accumulate;          // C += result (fp32 output only; always set when split-K)
-    int ksplit;              // k-tiles per z-slice
+    int ksplit;              // k-tiles per split-K slice
+    int nsplit;              // number of split-K slices (grid = tiles * nsplit, slice-major so a slice's tiles share an XCD)
     // dropout on (acc*alpha + bias), before the residual:  keep iff hash(seed, row*N+col) >= thresh
     unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the producing layer)
@@ -323,12 +324,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    const int t = xcd_remap(blockIdx.x, nblk);
+    const int tiles = tiles_n * ((p.M + BM - 1) / BM);
+    // XCD x (= blockIdx % 8) walks a contiguous range of (slice, tile) pairs, slice-major: the tiles of one split-K slice
+    // run on one XCD and share its L2 copy of that slice's operand slabs
+    const int q = xcd_remap(blockIdx.x, gridDim.x);
+    const int kz = q / tiles, t = q - kz * tiles;
     const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
     const int nk = (p.K + BK - 1) / BK;
-    const int kt0 = blockIdx.z * p.ksplit;
+    const int kt0 = kz * p.ksplit;
     const int kt1 = min(nk, kt0 + p.ksplit);
 
     const T* A = static_cast<const T*>(p.A);
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
     }
 
     // ---- epilogue (the main loop's trailing barrier has released the operand tiles: reuse them as scratch)
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = p.nsplit > 1;
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -391,7 +395,8 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     q.ksplit = (nk + splitk - 1) / splitk;
     if (q.ksplit < 1) q.ksplit = 1;
     const int z = nk > 0 ? (nk + q.ksplit - 1) / q.ksplit : 1;
-    dim3 grid(tiles, 1, z);
+    q.nsplit = z;
+    dim3 grid(tiles * z, 1, 1);
     hipLaunchKernelGGL((gemm_kernel<T, TO, TA, TB, AL>), grid, dim3(NTHREADS), 0, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm");
     return 0;
@@ -481,10 +486,12 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int q = xcd_remap(blockIdx.x, gridDim.x);
+    const int kz = q / tiles, t = q - kz * tiles;
     const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
     const int nk = p.K / BKE;
-    const int kt0 = blockIdx.z * p.ksplit;
+    const int kt0 = kz * p.ksplit;
     const int kt1 = min(nk, kt0 + p.ksplit);
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
         }
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = p.nsplit > 1;
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     __builtin_amdgcn_s_barrier();                       // every wave is done with the operand ring: reuse it as scratch
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
@@ -564,7 +571,8 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
     if (splitk > nk) splitk = nk;
     q.ksplit = (nk + splitk - 1) / splitk;
     const int z = (nk + q.ksplit - 1) / q.ksplit;
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, z), dim3(LTHREADS), SMEM, stream, q);
+    q.nsplit = z;
+    hipLaunchKernelGGL(kern, dim3(tiles * z, 1, 1), dim3(LTHREADS), SMEM, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm(large)");
     return 0;
 }
