@@ -177,6 +177,62 @@ __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) {
     return u.h;
 }
 
+// K/V tile staging for the bf16 kernels: tile 0 goes global -> LDS directly; every later tile is fetched into registers
+// while the previous tile is being consumed (later tiles exist only when T > 64, i.e. the block has >= 3 waves, so three
+// 16-byte pieces per thread always cover the 512 pieces of a K or V tile).
+struct KVRegs { u32x4 k[3], v[3]; };
+
+__device__ __forceinline__ void kv_fetch(KVRegs& r, const bf16_t* base, long RS, int HD, int kv0, int T, int tid, int nthr) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * nthr;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
+        if (idx < KT * 8) {
+            const int key = idx >> 3, c = idx & 7;
+            if (kv0 + key < T) {
+                const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
+                kv = *reinterpret_cast<const u32x4*>(rp + HD);
+                vv = *reinterpret_cast<const u32x4*>(rp + 2 * HD);
+            }
+        }
+        r.k[i] = kv; r.v[i] = vv;
+    }
+}
+
+__device__ __forceinline__ void kv_commit(const KVRegs& r, char* ldsK, char* ldsV, int vpitch, int tid, int nthr) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * nthr;
+        if (idx < KT * 8) {
+            const int key = idx >> 3, c = idx & 7;
+            *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = r.k[i];
+            *reinterpret_cast<u32x4*>(ldsV + key * vpitch + c * 16) = r.v[i];
+        }
+    }
+}
+
+__device__ __forceinline__ void kv_direct(const bf16_t* base, long RS, int HD, int kv0, int T, char* ldsK, char* ldsV, int vpitch,
+                                          int tid, int nthr) {
+    for (int idx = tid; idx < KT * 8; idx += nthr) {
+        const int key = idx >> 3, c = idx & 7;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
+        if (kv0 + key < T) {
+            const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
+            kv = *reinterpret_cast<const u32x4*>(rp + HD);
+            vv = *reinterpret_cast<const u32x4*>(rp + 2 * HD);
+        }
+        *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = kv;
+        *reinterpret_cast<u32x4*>(ldsV + key * vpitch + c * 16) = vv;
+    }
+}
+
+__device__ __forceinline__ void kbias_fill(float* kbias, const long* mask, int b, int kv0, int T, int tid) {
+    if (tid < KT) {
+        const int key = kv0 + tid;
+        kbias[tid] = (key < T && (!mask || mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+    }
+}
+
 __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * VP16 + KT * 4];
     char* ldsK = lds;
@@ -205,25 +261,15 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = NEG, lsum = 0.f;
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int HD = p.H * 64;
 
+    kv_direct(base, RS, HD, 0, T, ldsK, ldsV, VP16, tid, nthr);
+    kbias_fill(kbias, p.mask, b, 0, T, tid);
+    __syncthreads();
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
-        __syncthreads();
-        for (int idx = tid; idx < KT * 8; idx += nthr) {      // 64 keys x 8 chunks of 16 B, for K and V
-            const int key = idx >> 3, c = idx & 7;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
-            if (kv0 + key < T) {
-                const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
-                kv = *reinterpret_cast<const u32x4*>(rp + p.H * 64);
-                vv = *reinterpret_cast<const u32x4*>(rp + 2 * p.H * 64);
-            }
-            *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = kv;
-            *reinterpret_cast<u32x4*>(ldsV + key * VP16 + c * 16) = vv;
-        }
-        if (tid < KT) {
-            const int key = kv0 + tid;
-            kbias[tid] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
-        }
-        __syncthreads();
+        const bool more = kv0 + KT < T;
+        KVRegs nxt;
+        if (more) kv_fetch(nxt, base, RS, HD, kv0 + KT, T, tid, nthr);     // in flight during this tile's MFMAs
 
         f32x16 s[2];
 #pragma unroll
@@ -269,6 +315,12 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                 }
             }
+        }
+        if (more) {
+            __syncthreads();
+            kv_commit(nxt, ldsK, ldsV, VP16, tid, nthr);
+            kbias_fill(kbias, p.mask, b, kv0 + KT, T, tid);
+            __syncthreads();
         }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -352,24 +404,59 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const float scale = p.scale_log2e * 0.6931471805599453f;
 
-    for (int q0 = 0; q0 < T; q0 += QT) {
-        __syncthreads();
-        for (int idx = tid; idx < QT * 8; idx += nthr) {   // 32 queries x 8 chunks = 256 chunks each for Q and dO
-            const int qq = idx >> 3, c = idx & 7;
+    // Q / dO tiles of 32 queries: tile 0 directly, later tiles prefetched into registers during the previous tile's MFMAs
+    // (more than one tile means T > 32, i.e. >= 2 waves, so two 16-byte pieces per thread cover the 256 pieces)
+    auto qg_fetch = [&](int q0, u32x4 (&rq)[2], u32x4 (&rg)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * nthr;
             u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
-            if (q0 + qq < T) {
-                qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c * 8);
-                gv = *reinterpret_cast<const u32x4*>(gbase + (long)(q0 + qq) * OS + c * 8);
+            if (idx < QT * 8) {
+                const int qq = idx >> 3, c = idx & 7;
+                if (q0 + qq < T) {
+                    qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c * 8);
+                    gv = *reinterpret_cast<const u32x4*>(gbase + (long)(q0 + qq) * OS + c * 8);
+                }
             }
-            *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = qv;
-            *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = gv;
+            rq[i] = qv; rg[i] = gv;
+        }
+    };
+    auto qg_commit = [&](int q0, const u32x4 (&rq)[2], const u32x4 (&rg)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * nthr;
+            if (idx < QT * 8) {
+                const int qq = idx >> 3, c = idx & 7;
+                *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = rq[i];
+                *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = rg[i];
+            }
         }
         if (tid < QT) {
             const bool v = q0 + tid < T;
             lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + q0 + tid] : 1e30f;   // -> P = 0 for padded queries
             delq[tid] = v ? p.delta[((long)b * p.H + h) * T + q0 + tid] : 0.f;
         }
-        __syncthreads();
+    };
+    for (int idx = tid; idx < QT * 8; idx += nthr) {   // tile 0: 32 queries x 8 chunks for Q and dO
+        const int qq = idx >> 3, c = idx & 7;
+        u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
+        if (qq < T) {
+            qv = *reinterpret_cast<const u32x4*>(base + (long)qq * RS + c * 8);
+            gv = *reinterpret_cast<const u32x4*>(gbase + (long)qq * OS + c * 8);
+        }
+        *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = qv;
+        *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = gv;
+    }
+    if (tid < QT) {
+        const bool v = tid < T;
+        lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + tid] : 1e30f;
+        delq[tid] = v ? p.delta[((long)b * p.H + h) * T + tid] : 0.f;
+    }
+    __syncthreads();
+    for (int q0 = 0; q0 < T; q0 += QT) {
+        const bool more = q0 + QT < T;
+        u32x4 nq[2], ng[2];
+        if (more) qg_fetch(q0 + QT, nq, ng);
         // S[q][key], dP[q][key]: MFMA rows = queries (A from LDS), columns = keys (B = this lane's K / V row)
         f32x16 s, dp;
 #pragma unroll
@@ -409,6 +496,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
                 dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gf, dv[db], 0, 0, 0);
                 dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qf, dk[db], 0, 0, 0);
             }
+        }
+        if (more) {
+            __syncthreads();
+            qg_commit(q0 + QT, nq, ng);
+            __syncthreads();
         }
     }
     // dk/dv accumulators: rows = keys (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32
@@ -461,24 +553,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
 
+    const int HD = p.H * 64;
+    kv_direct(base, RS, HD, 0, T, ldsK, ldsV, KP16, tid, nthr);
+    kbias_fill(kbias, p.mask, b, 0, T, tid);
+    __syncthreads();
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
-        __syncthreads();
-        for (int idx = tid; idx < KT * 8; idx += nthr) {
-            const int key = idx >> 3, c = idx & 7;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = kv;
-            if (kv0 + key < T) {
-                const bf16_t* rp = base + (long)(kv0 + key) * RS + c * 8;
-                kv = *reinterpret_cast<const u32x4*>(rp + p.H * 64);
-                vv = *reinterpret_cast<const u32x4*>(rp + 2 * p.H * 64);
-            }
-            *reinterpret_cast<u32x4*>(ldsK + key * KP16 + c * 16) = kv;
-            *reinterpret_cast<u32x4*>(ldsV + key * KP16 + c * 16) = vv;
-        }
-        if (tid < KT) {
-            const int key = kv0 + tid;
-            kbias[tid] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
-        }
-        __syncthreads();
+        const bool more = kv0 + KT < T;
+        KVRegs nxt;
+        if (more) kv_fetch(nxt, base, RS, HD, kv0 + KT, T, tid, nthr);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kv0 + kb * 32 >= T) continue;
@@ -519,6 +601,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, kf, dq[db], 0, 0, 0);
                 }
             }
+        }
+        if (more) {
+            __syncthreads();
+            kv_commit(nxt, ldsK, ldsV, KP16, tid, nthr);
+            kbias_fill(kbias, p.mask, b, kv0 + KT, T, tid);
+            __syncthreads();
         }
     }
     // dq accumulators: rows = queries (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32

@@ -25,9 +25,16 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
-constexpr int KC_PITCH = 144;              // k-contiguous tile: 128 rows x (128 B + 16 B pad)
-constexpr int MC_PITCH = 320;              // transposed tile (bf16): 64 k-rows x (256 B + 64 B pad)
-constexpr int TILE_BYTES = 64 * MC_PITCH;  // 20480 >= 128 * 144
+constexpr int MC_PITCH = 320;              // transposed tile (bf16): k-rows x (256 B + 64 B pad)
+// KB = bytes of k per tile row (128 or 256).  k-contiguous tile: 128 rows x (KB + 16 B pad); transposed: KB/2 k-rows.
+template <int KB> struct Geo {
+    static constexpr int KC_PITCH = KB + 16;
+    static constexpr int NCH = KB / 16;                       // 16-byte chunks per row
+    static constexpr int LOADS = 128 * NCH / NTHREADS;        // 16-byte loads per thread per operand tile
+    static constexpr int KROWS = KB / 2;                      // k-rows of a transposed bf16 tile
+    static constexpr int TILE_BYTES = (128 * KC_PITCH > KROWS * MC_PITCH) ? 128 * KC_PITCH : KROWS * MC_PITCH;
+    static constexpr int KSTEPS = KB / 32;                    // MFMA k-steps (32 B of k per lane-half pair)
+};
 
 struct GemmParams {
     const void* A; const void* B; void* C;
@@ -56,16 +63,17 @@ template <> struct TT<float> { static constexpr int EPC = 4, BK = 32; };
 template <> struct TT<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 
 // ---- global -> register staging ----------------------------------------------------------------
-template <typename T, bool TRANS, bool AL = true>
-__device__ __forceinline__ void load_tile(u32x4 (&r)[4], const T* __restrict__ base, long ld, int row0, int lim,
+template <typename T, bool TRANS, bool AL, int KB>
+__device__ __forceinline__ void load_tile(u32x4 (&r)[Geo<KB>::LOADS], const T* __restrict__ base, long ld, int row0, int lim,
                                           int k0, int K, int tid) {
     constexpr int EPC = TT<T>::EPC;
+    constexpr int NCH = Geo<KB>::NCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < Geo<KB>::LOADS; ++i) {
         const int idx = tid + NTHREADS * i;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (!TRANS) {
-            const int rr = row0 + (idx >> 3), kk = k0 + (idx & 7) * EPC;
+            const int rr = row0 + idx / NCH, kk = k0 + (idx % NCH) * EPC;
             if constexpr (AL) {
                 if (rr < lim && kk < K) v = *reinterpret_cast<const u32x4*>(base + (long)rr * ld + kk);
             } else {            // arbitrary K / leading dimension (fp32 only): element loads with a K bound
@@ -88,22 +96,23 @@ __device__ __forceinline__ void load_tile(u32x4 (&r)[4], const T* __restrict__ b
     }
 }
 
-template <bool TRANS>
-__device__ __forceinline__ void store_tile(const u32x4 (&r)[4], char* lds, int tid) {
+template <bool TRANS, int KB>
+__device__ __forceinline__ void store_tile(const u32x4 (&r)[Geo<KB>::LOADS], char* lds, int tid) {
+    constexpr int NCH = Geo<KB>::NCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < Geo<KB>::LOADS; ++i) {
         const int idx = tid + NTHREADS * i;
-        const int off = TRANS ? (idx >> 4) * MC_PITCH + (idx & 15) * 16 : (idx >> 3) * KC_PITCH + (idx & 7) * 16;
+        const int off = TRANS ? (idx >> 4) * MC_PITCH + (idx & 15) * 16 : (idx / NCH) * Geo<KB>::KC_PITCH + (idx % NCH) * 16;
         *reinterpret_cast<u32x4*>(lds + off) = r[i];
     }
 }
 
 // ---- LDS -> MFMA fragment ---------------------------------------------------------------------
 // Returns the 16 bytes of k this lane feeds to the MFMA for tile row (row32 + lane%32), k-step kk.
-template <bool TRANS>
+template <bool TRANS, int KB>
 __device__ __forceinline__ u32x4 read_frag(const char* lds, int row32, int kk, int lane) {
     if (!TRANS) {
-        return *reinterpret_cast<const u32x4*>(lds + (row32 + (lane & 31)) * KC_PITCH + (2 * kk + (lane >> 5)) * 16);
+        return *reinterpret_cast<const u32x4*>(lds + (row32 + (lane & 31)) * Geo<KB>::KC_PITCH + (2 * kk + (lane >> 5)) * 16);
     } else {
         // ds_read_b64_tr_b16: every 16-lane group fetches a [4 k][16 m] block; lane a supplies the address of
         // 4 consecutive m of k-row (a / 4) and receives the 4 k values of column a.
@@ -314,12 +323,14 @@ __device__ __forceinline__ bool epilogue_vec_ok(const GemmParams& p, int out_ele
     return ok;
 }
 
-template <typename T, typename TO, bool TA, bool TB, bool AL = true>
-__global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+template <typename T, typename TO, bool TA, bool TB, bool AL = true, int KB = 128>
+__global__ __launch_bounds__(NTHREADS, KB == 128 ? 3 : 2) void gemm_kernel(GemmParams p) {
+    constexpr int TILE_BYTES = Geo<KB>::TILE_BYTES;
+    static_assert(2 * TILE_BYTES >= 4 * EP_WAVE_FLOATS * 4, "operand tiles double as epilogue scratch");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ldsA = lds;
     char* ldsB = lds + TILE_BYTES;
-    constexpr int BK = TT<T>::BK;
+    constexpr int BK = KB / (int)sizeof(T);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -346,26 +357,26 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4], rb[4];
+    u32x4 ra[Geo<KB>::LOADS], rb[Geo<KB>::LOADS];
     if (kt0 < kt1) {
-        load_tile<T, TA, AL>(ra, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
-        load_tile<T, TB, AL>(rb, B, p.ldb, n0, p.N, kt0 * BK, p.K, tid);
+        load_tile<T, TA, AL, KB>(ra, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
+        load_tile<T, TB, AL, KB>(rb, B, p.ldb, n0, p.N, kt0 * BK, p.K, tid);
     }
     for (int kt = kt0; kt < kt1; ++kt) {
-        store_tile<TA>(ra, ldsA, tid);
-        store_tile<TB>(rb, ldsB, tid);
+        store_tile<TA, KB>(ra, ldsA, tid);
+        store_tile<TB, KB>(rb, ldsB, tid);
         __syncthreads();
         if (kt + 1 < kt1) {
-            load_tile<T, TA, AL>(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
-            load_tile<T, TB, AL>(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+            load_tile<T, TA, AL, KB>(ra, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+            load_tile<T, TB, AL, KB>(rb, B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < Geo<KB>::KSTEPS; ++kk) {
             u32x4 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<TA>(ldsA, wm * 64 + i * 32, kk, lane);
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<TA, KB>(ldsA, wm * 64 + i * 32, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<TB>(ldsB, wn * 64 + j * 32, kk, lane);
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<TB, KB>(ldsB, wn * 64 + j * 32, kk, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -384,9 +395,17 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmParams p) {
     flush_colsum(p, cs, n0 + wn * 64, lane);
 }
 
-template <typename T, typename TO, bool TA, bool TB, bool AL = true>
+template <typename T, typename TO, bool TA, bool TB, bool AL = true, int KB = 128>
 int launch(const GemmParams& p, int splitk, hipStream_t stream) {
-    constexpr int BK = TT<T>::BK;
+    constexpr int BK = KB / (int)sizeof(T);
+    constexpr int SMEM = 2 * Geo<KB>::TILE_BYTES;
+    static bool configured = false;
+    if (!configured && SMEM > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, TO, TA, TB, AL, KB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
+        configured = true;
+    }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int nk = (p.K + BK - 1) / BK;
     GemmParams q = p;
@@ -397,7 +416,7 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     const int z = nk > 0 ? (nk + q.ksplit - 1) / q.ksplit : 1;
     q.nsplit = z;
     dim3 grid(tiles * z, 1, 1);
-    hipLaunchKernelGGL((gemm_kernel<T, TO, TA, TB, AL>), grid, dim3(NTHREADS), 0, stream, q);
+    hipLaunchKernelGGL((gemm_kernel<T, TO, TA, TB, AL, KB>), grid, dim3(NTHREADS), SMEM, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm");
     return 0;
 }
@@ -594,6 +613,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
     if (v == 3) return launch_large<TO, TA, TB, 32, 4, 256, 256, 2, 4, 2>(p, splitk, s);
     if (v == 4) return launch_large<TO, TA, TB, 32, 3, 256, 128, 4, 2, 4>(p, splitk, s);
+    if (v == 5 && aligned && p.K % 128 == 0) return launch<bf16_t, TO, TA, TB, true, 256>(p, splitk, s);
     return launch<bf16_t, TO, TA, TB>(p, splitk, s);
 }
 
