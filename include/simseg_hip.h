@@ -89,6 +89,10 @@ int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* o
                          float* delta, void* dqkv, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
                          float drop_p, void* stream);
 
+/* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).
+ * tools/seg_evaluation.py:71-73 (class_embeddings.mean(dim=0); /= norm()). */
+int simseg_segment_mean_l2norm(const float* x, float* out, int64_t S, int64_t P, int64_t D, void* stream);
+
 /* rnorm[r] = 1 / max(||x_r||_2, eps): the F.normalize of tools/seg_evaluation.py:112 as a GEMM row scale. */
 int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t rows, int64_t D, float eps, void* stream);
 

@@ -363,6 +363,18 @@ __global__ void topk_pool_bwd_kernel(const float* __restrict__ demb, const float
     }
 }
 
+// Prompt-ensemble reduction of the zero-shot classifier (tools/seg_evaluation.py:71-73): out[s,:] = normalize(mean_p x[s,p,:])
+__global__ void segment_mean_l2norm_kernel(const float* __restrict__ x, float* __restrict__ out, int Pn, int D) {
+    __shared__ float sh[16];
+    const int sgm = blockIdx.x, c = threadIdx.x;
+    const float* base = x + (long)sgm * Pn * D + c;
+    float acc = 0.f;
+    for (int i = 0; i < Pn; ++i) acc += base[(long)i * D];
+    acc /= Pn;
+    const float nrm = sqrtf(block_sum(acc * acc, sh));
+    out[(long)sgm * D + c] = acc / nrm;
+}
+
 // rnorm[row] = 1 / max(||x_row||, eps)   (F.normalize, tools/seg_evaluation.py:112); one wave per row
 template <typename TI>
 __global__ __launch_bounds__(256) void row_rnorm_kernel(const TI* __restrict__ x, float* __restrict__ rn, long rows, int D, float eps) {
@@ -553,6 +565,15 @@ extern "C" int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, 
     else
         hipLaunchKernelGGL(topk_pool_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, demb, emb, norm, idx, (bf16_t*)dtok, (int)N, (int)P, k, eps, normalize);
     SS_LAUNCH_CHECK("topk_pool_bwd");
+    return 0;
+}
+
+extern "C" int simseg_segment_mean_l2norm(const float* x, float* out, int64_t S, int64_t P, int64_t D, void* stream) {
+    SS_CHECK(x && out, "segment_mean_l2norm: null pointer");
+    SS_CHECK(D % 64 == 0 && D <= 1024 && P >= 1, "segment_mean_l2norm: D must be a multiple of 64 and <= 1024");
+    if (S <= 0) return 0;
+    hipLaunchKernelGGL(segment_mean_l2norm_kernel, dim3((unsigned)S), dim3((unsigned)D), 0, STREAM, x, out, (int)P, (int)D);
+    SS_LAUNCH_CHECK("segment_mean_l2norm");
     return 0;
 }
 

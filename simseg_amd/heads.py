@@ -113,3 +113,18 @@ def retrieval_recalls(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
     if int(c[0]) == 0:
         raise AssertionError("no left row has a matching right row")
     return {f"R@{b}": float(c[i + 1]) / float(c[0]) for i, b in enumerate(bounds)}
+
+
+@torch.no_grad()
+def class_text_embeddings(model, input_ids, attention_mask, chunk=2048):
+    """Zero-shot classifier weights (tools/seg_evaluation.py:57-75) as batched calls: input_ids / attention_mask are
+    [C, P, L] (C classes x P prompt templates); the text tower runs over C*P captions in chunks and one kernel reduces the
+    prompt ensemble (mean over P, re-normalise).  Returns [C, proj_dim] unit-norm rows."""
+    C, Pn, L = input_ids.shape
+    ids, mask = input_ids.reshape(C * Pn, L), attention_mask.reshape(C * Pn, L)
+    embs = []
+    for s in range(0, C * Pn, chunk):
+        feats = model.forward_text_feature(ids[s:s + chunk], mask[s:s + chunk])
+        embs.append(model.forward_text_project(feats, mask[s:s + chunk]))
+    emb = torch.cat(embs).float().view(C, Pn, -1)
+    return ops.segment_mean_l2norm(emb.contiguous())

@@ -166,6 +166,15 @@ def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=
     return dqkv
 
 
+def segment_mean_l2norm(x):
+    """[S,P,D] fp32 -> [S,D]: unit-norm mean over P."""
+    require_gpu(x)
+    S, Pn, D = x.shape
+    out = torch.empty(S, D, device=x.device, dtype=torch.float32)
+    call("simseg_segment_mean_l2norm", ptr(_c(x)), ptr(out), S, Pn, D, stream())
+    return out
+
+
 def row_rnorm(x2d, eps=1e-12):
     require_gpu(x2d)
     rn = torch.empty(x2d.shape[0], device=x2d.device, dtype=torch.float32)

@@ -188,3 +188,25 @@ def test_seg_similarity_map_vs_reference_golden(golden, monkeypatch):
     assert _maxerr(maps, tt(g["maps"])) < 1e-5
     sim16 = patch_text_similarity(tt(g["proj"]).cuda(), tt(g["text"]).cuda(), compute_dtype=torch.bfloat16)
     assert _maxerr(sim16, sim) < 2e-2
+
+
+def test_class_text_embeddings_prompt_ensemble(golden, monkeypatch):
+    """Batched zero-shot classifier == the per-class loop of tools/seg_evaluation.py:57-75 evaluated with the oracle."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    from oracle import simseg_ref as R
+    from simseg_amd.heads import class_text_embeddings
+    m = _build(golden).eval()
+    g = golden("clip_glue")
+    ref = R.RefCLIP("vit_test_patch16", "bert-test", img_size=96)
+    ref.load_state_dict({k[3:]: tt(g[k]) for k in g.files if k.startswith("sd.")}, strict=False)
+    ref.eval()
+    C, P, L = 5, 7, 25
+    ids, mask = R.synthetic_text(C * P, L, 1000, seed=9)
+    got = class_text_embeddings(m, ids.view(C, P, L).cuda(), mask.view(C, P, L).cuda(), chunk=16)
+    want = []
+    with torch.no_grad():
+        for c in range(C):
+            sl = slice(c * P, (c + 1) * P)
+            e = ref.forward_text_project(ref.forward_text_feature(ids[sl], mask[sl]), mask[sl]).mean(dim=0)
+            want.append(e / e.norm())
+    assert _maxerr(got, torch.stack(want)) < 1e-3
