@@ -187,6 +187,10 @@ template <typename TO>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16& accL, const f32x16& accR, float* wlds, int row0,
                                                int col0, int lane, bool atomic, bool vec_ok, float (&cs)[8]) {
     const int h2 = lane >> 5, cl = lane & 31;
+    if (p.accumulate == -1) {          // debug: epilogue skipped (keeps the accumulators live), for fixed-cost attribution
+        if (accL[0] + accR[0] == 12345.678f) static_cast<TO*>(p.C)[0] = (TO)1.f;
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h2;
@@ -213,7 +217,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
             return;
         }
     }
-#pragma unroll
+    // deliberately NOT unrolled: the body is large (8-wide GELU / GELU' / dropout / residual variants) and an unrolled,
+    // 4x-inlined epilogue overflowed the instruction cache (tens of microseconds of fetch stalls per tile, measured)
+#pragma unroll 1
     for (int t = 0; t < 4; ++t) {
         const int q = lane + 64 * t;
         const int rr = q >> 3, c8 = (q & 7) * 8;
@@ -274,8 +280,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[e] += v[e];
         } else {
-            for (int e = 0; e < 8 && col + e < p.N; ++e) {
-                float x = v[e] * rs + (p.bias ? p.bias[col + e] : 0.f);
+#pragma unroll 1
+            for (int e = 0; e < 8 && col + e < p.N; ++e) {      // edge / unaligned columns: rolled, element-wise
+                float x = wlds[rr * EP_PITCH + c8 + e] * rs + (p.bias ? p.bias[col + e] : 0.f);
                 if (p.act == 1) {
                     if (aux_out) st_out(aux_out + o + e, x);
                     x = gelu_erf(x);
@@ -390,8 +397,12 @@ __global__ __launch_bounds__(NTHREADS, KB == 128 ? 3 : 2) void gemm_kernel(GemmP
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    epilogue_block<TO>(p, acc[0][0], acc[0][1], wlds, m0 + wm * 64, n0 + wn * 64, lane, atomic, vec_ok, cs);
-    epilogue_block<TO>(p, acc[1][0], acc[1][1], wlds, m0 + wm * 64 + 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {         // rolled: one copy of the (large) epilogue body in the instruction stream
+        f32x16 l = acc[0][0], r = acc[0][1];
+        if (i == 1) { l = acc[1][0]; r = acc[1][1]; }
+        epilogue_block<TO>(p, l, r, wlds, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+    }
     flush_colsum(p, cs, n0 + wn * 64, lane);
 }
 
@@ -502,6 +513,8 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     constexpr int FM = TM / WM_ / 32, FN = TN / WN_ / 32;
     static_assert(FN == 2, "the epilogue stages 64-column blocks");
     static_assert(NSTAGE * STAGE >= 8 * EP_WAVE_FLOATS * 4, "operand ring doubles as epilogue scratch");
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+    unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     const int tiles_n = (p.N + TN - 1) / TN;
@@ -532,6 +545,7 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
         }
     }
     int stage = 0;
+    dbg_t1 = __builtin_readcyclecounter();
     for (int kt = kt0; kt < kt1; ++kt) {
         // slab kt must have landed; up to NSTAGE-2 younger slabs may stay in flight
         const int ahead = min(NSTAGE - 2, kt1 - 1 - kt);
@@ -540,6 +554,7 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == kt0) dbg_t2 = __builtin_readcyclecounter();
         const int nxt = kt + NSTAGE - 1;
         if (nxt < kt1) {
             int ns = stage + NSTAGE - 1; ns = ns >= NSTAGE ? ns - NSTAGE : ns;
@@ -565,12 +580,22 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     const bool atomic = p.nsplit > 1;
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     __builtin_amdgcn_s_barrier();                       // every wave is done with the operand ring: reuse it as scratch
+    dbg_t3 = __builtin_readcyclecounter();
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < FM; ++i) {        // rolled: one copy of the (large) epilogue body in the instruction stream
+        f32x16 l = acc[0][0], r = acc[0][1];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
-        epilogue_block<TO>(p, acc[i][0], acc[i][1], wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+        for (int ii = 1; ii < FM; ++ii)
+            if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
+        epilogue_block<TO>(p, l, r, wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+    }
     flush_colsum(p, cs, n0 + wn * 64, lane);
+    if (p.accumulate == -1 && blockIdx.x == 0 && tid == 0) {     // debug timeline (cycle counter) of block 0 / wave 0
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.C);
+        d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t2 - dbg_t1; d[2] = dbg_t3 - dbg_t2; d[3] = __builtin_readcyclecounter() - dbg_t3;
+    }
 }
 
 template <typename TO, bool TA, bool TB, int BKE, int NSTAGE, int TM, int TN, int WM_, int WN_, int MINW>
@@ -596,6 +621,122 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
+
+// =================================================================================================================
+// Persistent variant of the 256x256 direct-to-LDS kernel: one block per CU walks a contiguous (per XCD) list of tiles.
+// The first K-slab of the NEXT tile is issued before the current tile's epilogue, so its fetch latency is hidden by
+// the epilogue and the epilogue's stores drain underneath the next tile's main loop -- the two fixed costs that make
+// the one-shot 256x256 kernel lose to the 128x128 kernel at K = 768.  The epilogue scratch is the stage that has just
+// been consumed (plus 8 KiB of padding on that side); the other stage is receiving the prefetched slab.
+// =================================================================================================================
+template <typename TO, bool TA, bool TB>
+__global__ __launch_bounds__(LTHREADS, 2) void gemm_persist_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    constexpr int BKE = 64, TM = 256, TN = 256, WN_ = 4;
+    constexpr int SLAB = TM * BKE * 2, STAGE = 2 * SLAB;        // 32 KiB, 64 KiB
+    constexpr int PAD = 8192;
+    static_assert(STAGE + PAD >= 8 * EP_WAVE_FLOATS * 4, "one stage + pad holds the epilogue scratch of 8 waves");
+    char* const stage0 = lds_raw + PAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN_, wn = wave % WN_;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int nk = p.K / BKE;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
+
+    // tile list of this block: XCD x = blockIdx % 8 owns tiles [lo, hi); its blocks take them round-robin
+    const int nxcd = 8, x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q8 = tiles / nxcd, r8 = tiles % nxcd;
+    const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+    const int hi = lo + (x < r8 ? q8 + 1 : q8);
+
+    int t = lo + j;
+    if (t >= hi) return;
+    int st = 0;
+    {
+        const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
+        glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, 0, stage0, wave, lane);
+        glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, 0, stage0 + SLAB, wave, lane);
+    }
+    for (; t < hi; t += per) {
+        const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
+        const int tn = t + per;
+        f32x16 acc[4][2];
+        {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = zero;
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            char* nxt = stage0 + (st ^ 1) * STAGE;
+            if (kt + 1 < nk) {
+                glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, (kt + 1) * BKE, nxt, wave, lane);
+                glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, (kt + 1) * BKE, nxt + SLAB, wave, lane);
+            } else if (tn < hi) {       // cross-tile prefetch: the next tile's first slab
+                const int m1 = (tn / tiles_n) * TM, n1 = (tn % tiles_n) * TN;
+                glds_slab<BKE, TA, TM>(A, p.lda, m1, p.M, 0, nxt, wave, lane);
+                glds_slab<BKE, TB, TN>(B, p.ldb, n1, p.N, 0, nxt + SLAB, wave, lane);
+            }
+            const char* sa = stage0 + st * STAGE;
+            const char* sb = sa + SLAB;
+#pragma unroll
+            for (int kk = 0; kk < BKE / 16; ++kk) {
+                u32x4 fa[4], fb[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) fb[jj] = read_frag_l<BKE, TB, TN>(sb, wn * 64 + jj * 32, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = read_frag_l<BKE, TA, TM>(sa, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) mma<bf16_t>(acc[i][jj], fa[i], fb[jj]);
+            }
+            st ^= 1;
+        }
+        // the stage consumed last (st ^ 1) is free once every wave has passed this barrier; the other one is being filled
+        __builtin_amdgcn_s_barrier();
+        char* scratch = (st ^ 1) == 0 ? lds_raw : stage0 + STAGE;          // [pad | stage0]  or  [stage1 | pad]
+        float* wlds = reinterpret_cast<float*>(scratch) + wave * EP_WAVE_FLOATS;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            f32x16 l = acc[0][0], r = acc[0][1];
+#pragma unroll
+            for (int ii = 1; ii < 4; ++ii)
+                if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
+            epilogue_block<TO>(p, l, r, wlds, m0 + wm * 128 + i * 32, n0 + wn * 64, lane, false, vec_ok, cs);
+        }
+        flush_colsum(p, cs, n0 + wn * 64, lane);
+    }
+}
+
+template <typename TO, bool TA, bool TB>
+int launch_persist(const GemmParams& p, hipStream_t stream) {
+    constexpr int SMEM = 2 * 65536 + 2 * 8192;
+    static bool configured = false;
+    auto kern = gemm_persist_kernel<TO, TA, TB>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
+        configured = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    int grid = tiles < 256 ? ((tiles + 7) / 8) * 8 : 256;      // a multiple of 8 blocks: the same count on every XCD
+    GemmParams q = p;
+    q.ksplit = p.K / 64; q.nsplit = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LTHREADS), SMEM, stream, q);
+    SS_LAUNCH_CHECK("simseg_gemm(persistent)");
+    return 0;
+}
+
+int g_gemm_debug_skip_epilogue = 0;
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 BK64 x2 stages, 3 = 256x256 BK32 x4-stage ring,
 //          4 = 256x128 BK32 x3-stage ring at 2 blocks/CU
 int g_gemm_variant = 0;
@@ -606,21 +747,25 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     int v = g_gemm_variant;
     const int nk64 = p.K / 64;
     const int kper = (nk64 + (splitk > 1 ? splitk : 1) - 1) / (splitk > 1 ? splitk : 1);   // 64-deep slabs per block
-    // measured (profiles/r1_gemm_variants.txt): the 256x256 tile wins for k-contiguous A once its fixed cost is amortised
-    // over >= 48 slabs (K >= 3072); split-K wgrad and K = 768 are faster on the 128x128 kernel (3 blocks/CU overlap)
-    if (v == 0) v = (big_ok && !TA && kper >= 48) ? 2 : 1;
+    // measured (profiles/r1_gemm_variants.txt, after the epilogue was rolled to fit the instruction cache): the 256x256
+    // direct-to-LDS kernel wins for k-contiguous A from K >= 768 on when there is at least one tile per CU; split-K wgrad
+    // (transposed A) and small problems stay on the 128x128 kernel (3 blocks/CU, more blocks to spread)
+    const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 256) ? 2 : 1;
     if (!big_ok) v = 1;
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
     if (v == 3) return launch_large<TO, TA, TB, 32, 4, 256, 256, 2, 4, 2>(p, splitk, s);
     if (v == 4) return launch_large<TO, TA, TB, 32, 3, 256, 128, 4, 2, 4>(p, splitk, s);
     if (v == 5 && aligned && p.K % 128 == 0) return launch<bf16_t, TO, TA, TB, true, 256>(p, splitk, s);
+    if (v == 6 && splitk <= 1) return launch_persist<TO, TA, TB>(p, s);
     return launch<bf16_t, TO, TA, TB>(p, splitk, s);
 }
 
 }  // namespace
 
 extern "C" int simseg_set_gemm_variant(int v) {
-    g_gemm_variant = v;
+    g_gemm_debug_skip_epilogue = v >= 100;
+    g_gemm_variant = v % 100;
     return 0;
 }
 
@@ -657,7 +802,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.A = A; p.B = B; p.C = C; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.bias = bias; p.rowscale = rowscale;
     p.residual = residual; p.ldr = ldr; p.act = act; p.aux = aux; p.aux_out = aux_out;
-    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = accumulate;
+    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = g_gemm_debug_skip_epilogue ? -1 : accumulate;
     p.drop_seed = drop_seed;
     p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
