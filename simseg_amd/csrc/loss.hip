@@ -184,6 +184,29 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Multi-tensor form: one launch for every parameter tensor.  table[t] = {p, g, m, v} device pointers, sizes[t] elements;
+// chunk c of the launch covers elements [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tid[c].
+struct AdamTensors { float* p; const float* g; float* m; float* v; };
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __restrict__ table, const long* __restrict__ sizes,
+                                                          const int* __restrict__ chunk_tid, const long* __restrict__ chunk_off,
+                                                          int chunk, float lr, float b1, float b2, float eps, const float* __restrict__ wd,
+                                                          float bc1, float bc2_sqrt, float grad_scale) {
+    const int c = blockIdx.x;
+    const int t = chunk_tid[c];
+    const AdamTensors T = table[t];
+    const long lo = chunk_off[c];
+    const long hi = min(sizes[t], lo + chunk);
+    const float decay = 1.0f - lr * wd[t];
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float gi = T.g[i] * grad_scale;
+        float pi = T.p[i] * decay;
+        const float mi = b1 * T.m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * T.v[i] + (1.0f - b2) * gi * gi;
+        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        T.p[i] = pi; T.m[i] = mi; T.v[i] = vi;
+    }
+}
+
 }  // namespace
 
 #define STREAM ((hipStream_t)stream)
@@ -242,6 +265,20 @@ extern "C" int simseg_recall_counts(const int32_t* has_match, const int32_t* ran
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(recall_count_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, has_match, rank, (long)M, b0, b1, b2, counts4);
     SS_LAUNCH_CHECK("recall_counts");
+    return 0;
+}
+
+extern "C" int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
+                                       int64_t n_chunks, int chunk, float lr, float beta1, float beta2, float eps,
+                                       const float* weight_decay, int64_t step, float grad_scale, void* stream) {
+    SS_CHECK(table && sizes && chunk_tid && chunk_off && weight_decay, "adamw_multi_step: null pointer");
+    SS_CHECK(step >= 1 && chunk > 0, "adamw_multi_step: bad step/chunk");
+    if (n_chunks <= 0) return 0;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, STREAM, (const AdamTensors*)table, (const long*)sizes,
+                       (const int*)chunk_tid, (const long*)chunk_off, chunk, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    SS_LAUNCH_CHECK("adamw_multi_step");
     return 0;
 }
 

@@ -56,7 +56,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         e1.record()
         kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
         kind += "_o32" if out.dtype == torch.float32 else "_o16"
-        if a.dtype == torch.bfloat16 and not trans_a and K >= 3072 and M >= 256 and N >= 128:
+        if (a.dtype == torch.bfloat16 and not trans_a and K >= 768 and K % 64 == 0 and M >= 256 and N >= 128
+                and ((M + 255) // 256) * ((N + 255) // 256) >= 256):
             kind += "_L"          # the dispatcher's rule for the 256x256 direct-to-LDS kernel (csrc/gemm.hip dispatch_bf16)
         PROFILE.append((kind, 2.0 * M * N * K, e0, e1))
     return out

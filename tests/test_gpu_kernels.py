@@ -395,3 +395,20 @@ def test_adamw_step(ops):
         ops.adamw_step(p, g * step, m, v, p16, 1e-3, (0.9, 0.98), 1e-6, 1e-3, step)
     _close(p, ref.detach(), 1e-6, "adamw")
     assert torch.equal(p16, p.bfloat16())
+
+
+def test_adamw_multi_tensor_optimizer():
+    """simseg_amd.optim.AdamW (one launch for all tensors) == torch.optim.AdamW over several steps and shapes."""
+    from simseg_amd.optim import AdamW
+    shapes = [(768, 768), (3072,), (1, 197, 768), (), (70000, 3)]
+    ours = [torch.nn.Parameter(_rand(*s, seed=i) if s else torch.tensor(0.02, device="cuda")) for i, s in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    o1 = AdamW(ours, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-2)
+    o2 = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-2)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            g = _rand(*shapes[i], seed=100 * step + i) if shapes[i] else torch.tensor(0.3 * (step + 1), device="cuda")
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step(); o2.step()
+    for a, b in zip(ours, ref):
+        _close(a.detach(), b.detach(), 1e-5, "multi-tensor adamw")

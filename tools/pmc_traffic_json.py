@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""profiles/r1_pmc_fetch_size.txt + r1_pmc_write_size.txt (tools/pmc_stats.py output of the two rocprofv3 --pmc passes of
+bench.py) -> profiles/r1_pmc_traffic.json keyed by the GEMM kinds bench.py reports."""
+import json
+import re
+import sys
+
+
+def parse(path, counter):
+    out, cur = {}, None
+    for line in open(path):
+        if line.startswith("_Z") or line.startswith("__"):
+            cur = line.strip()
+        elif counter in line:
+            out[cur] = float(line.split("avg/dispatch")[1].split()[0])
+    return out
+
+
+def kind_of(name):
+    m = re.search(r"gemm_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)E", name)
+    large = False
+    if not m:
+        m2 = re.search(r"gemm_large_kernelI(DF16b|f)Lb(\d)ELb(\d)E", name)
+        if not m2:
+            return None
+        tin, tout, ta, tb, large = "DF16b", m2.group(1), m2.group(2), m2.group(3), True
+    else:
+        tin, tout, ta, tb = m.groups()
+    k = ("bf16" if tin == "DF16b" else "f32") + "_" + ("t" if ta == "1" else "n") + ("n" if tb == "1" else "t")
+    k += "_o16" if tout == "DF16b" else "_o32"
+    return k + ("_L" if large else "")
+
+
+def main(prefix="profiles/r1"):
+    f, w = parse(prefix + "_pmc_fetch_size.txt", "FETCH_SIZE"), parse(prefix + "_pmc_write_size.txt", "WRITE_SIZE")
+    res = {}
+    for name, fetch in f.items():
+        k = kind_of(name)
+        if k:
+            res[k] = {"kernel": name, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": w.get(name),
+                      "hbm_bytes_per_launch": int((2 * fetch + (w.get(name) or 0)) * 1024)}
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-seg",
+               "note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
+                       "wide coalesced read); WRITE_SIZE is uncalibrated there", "per_kind": res}, open(prefix + "_pmc_traffic.json", "w"), indent=1)
+    for k, v in sorted(res.items()):
+        print(f"{k:18s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
