@@ -37,6 +37,13 @@ int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int
                 int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, float* colsum,
                 void* stream);
 
+/* K14, the dense zero-shot segmentation map: out[m,c] = < x[m,:] / max(||x[m,:]||, eps), text[c,:] > for every patch row m
+ * and every class c (C <= 256) in one pass over x, the row L2-normalisation (F.normalize, tools/seg_evaluation.py:112) fused
+ * into the MFMA kernel; normalize=0 gives the plain x . text^T.  Replaces the per-class GEMV loop of
+ * tools/seg_evaluation.py:128-139.  x[M,K], text[C,K] in `dtype` (0 fp32 exact, 1 bf16), out fp32 [M,C]. */
+int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M, int64_t C, int64_t K, int dtype, float eps,
+                          int normalize, void* stream);
+
 /* Kernel selection for benchmarking: 0 auto, 1 128x128 register-staged, 2 256x256 BK64x2, 3 256x256 BK32x4 ring. */
 int simseg_set_gemm_variant(int v);
 

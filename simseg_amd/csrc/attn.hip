@@ -620,6 +620,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
         }
 }
 
+// Waves (= 32-query tiles) per block.  The kernels hold 2-3 waves per SIMD (register bound), i.e. 8-12 waves per CU:
+// blocks of 3, 4 or 6 waves tile that exactly, while a 7- or 8-wave block would leave almost half the CU's wave slots
+// empty.  Among those, pick the size that wastes the fewest wave slots on padding (ties: the larger block, which
+// re-stages K/V less often).
+int attn_waves_per_block(int q32) {
+    if (q32 <= 4) return q32;
+    int best = 4, best_pad = ((q32 + 3) / 4) * 4 - q32;
+    const int cand[2] = {6, 3};
+    for (int c : cand) {       // measured (profiles/r1_kernel_roofline.txt): fewest padded slots wins; 6-wave blocks only on a tie
+        const int pad = ((q32 + c - 1) / c) * c - q32;
+        if (pad < best_pad || (pad == best_pad && c > best)) { best = c; best_pad = pad; }
+    }
+    return best;
+}
+
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
                 uint64_t seed, float drop_p) {
     SS_CHECK(qkv, "attention: null qkv");
@@ -647,7 +662,7 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     p.out = out; p.lse = lse;
     // one wave per 32 queries; a block holds up to 8 waves of the same (batch, head) so K/V tiles are staged once
     const int q32 = (int)((T + 31) / 32);
-    const int nw = q32 < 8 ? q32 : ((q32 % 7 == 0 || q32 % 7 > q32 % 8) && q32 % 8 != 0 ? 7 : 8);
+    const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
     if (dtype == 0)
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
@@ -670,7 +685,7 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                        (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
     const int q32 = (int)((T + 31) / 32);
-    const int nw = q32 < 8 ? q32 : ((q32 % 7 == 0 || q32 % 7 > q32 % 8) && q32 % 8 != 0 ? 7 : 8);
+    const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(nw * 64), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(nw * 64), 0, s, p);

@@ -406,6 +406,107 @@ __global__ __launch_bounds__(NTHREADS, KB == 128 ? 3 : 2) void gemm_kernel(GemmP
     flush_colsum(p, cs, n0 + wn * 64, lane);
 }
 
+// =================================================================================================================
+// K14: dense patch x class-text similarity map with the row L2-normalisation fused in.
+//   out[m, c] = < x[m,:] / max(||x[m,:]||, eps),  text[c,:] >        (tools/seg_evaluation.py:112 + :136 for every class)
+// One block = 128 patch rows x ALL classes (C <= 32*NT <= 256), 4 waves of 32 rows each; the class matrix tile stays in
+// LDS for the whole block, every A fragment is read once and feeds NT MFMAs, and the sum of squares of each row is
+// accumulated from the very fragments that feed the MFMAs -- x is read exactly once from HBM.
+// =================================================================================================================
+template <typename T, int NT>
+__global__ __launch_bounds__(NTHREADS) void simmap_kernel(const T* __restrict__ x, const T* __restrict__ text, float* __restrict__ out,
+                                                          int M, int C, int K, float eps, int normalize) {
+    constexpr int KB = 128;
+    constexpr int BK = KB / (int)sizeof(T);
+    constexpr int PITCH = Geo<KB>::KC_PITCH;
+    constexpr int NB = (NT + 3) / 4;                  // 128-row slabs of the class tile
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ldsA = lds;
+    char* ldsB = lds + 128 * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    f32x16 acc[NT];
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = zero;
+    }
+    float ss = 0.f;
+    u32x4 ra[4], rb[NB][4];
+    const int nk = (K + BK - 1) / BK;
+    load_tile<T, false, true, KB>(ra, x, K, m0, M, 0, K, tid);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_tile<T, false, true, KB>(rb[b], text, K, b * 128, C, 0, K, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile<false, KB>(ra, ldsA, tid);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) store_tile<false, KB>(rb[b], ldsB + b * 128 * PITCH, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_tile<T, false, true, KB>(ra, x, K, m0, M, (kt + 1) * BK, K, tid);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) load_tile<T, false, true, KB>(rb[b], text, K, b * 128, C, (kt + 1) * BK, K, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x4 fa = read_frag<false, KB>(ldsA, wave * 32, kk, lane);
+            if constexpr (sizeof(T) == 4) {
+                union { u32x4 v; float f[4]; } u; u.v = fa;
+                ss += u.f[0] * u.f[0] + u.f[1] * u.f[1] + u.f[2] * u.f[2] + u.f[3] * u.f[3];
+            } else {
+                union { u32x4 v; bf16x8 h; } u; u.v = fa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)u.h[e]; ss += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                // A operand = class rows (MFMA rows), B operand = patch rows (MFMA columns): the accumulator then holds one
+                // PATCH per lane and 16 classes per lane, so the row scale is lane-local and a lane's 4-register groups are
+                // 4 consecutive classes of one output row
+                const u32x4 fb = read_frag<false, KB>(ldsB, j * 32, kk, lane);
+                mma<T>(acc[j], fb, fa);
+            }
+        }
+        __syncthreads();
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rn = normalize ? 1.0f / fmaxf(sqrtf(ss), eps) : 1.0f;
+    const int row = m0 + wave * 32 + (lane & 31);
+    if (row < M) {
+        float* orow = out + (long)row * C;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                if (c < C) orow[c] = acc[j][r] * rn;
+            }
+    }
+}
+
+template <typename T, int NT>
+int launch_simmap(const T* x, const T* text, float* out, int M, int C, int K, float eps, int normalize, hipStream_t stream) {
+    constexpr int SMEM = (128 + ((NT + 3) / 4) * 128) * Geo<128>::KC_PITCH;
+    hipLaunchKernelGGL((simmap_kernel<T, NT>), dim3((M + 127) / 128), dim3(NTHREADS), SMEM, stream, x, text, out, M, C, K, eps, normalize);
+    SS_LAUNCH_CHECK("simseg_patch_text_sim");
+    return 0;
+}
+
+template <typename T>
+int dispatch_simmap(const void* x, const void* text, float* out, int M, int C, int K, float eps, int normalize, hipStream_t s) {
+    const T* a = static_cast<const T*>(x);
+    const T* b = static_cast<const T*>(text);
+    const int nt = (C + 31) / 32;
+    switch (nt) {
+        case 1: return launch_simmap<T, 1>(a, b, out, M, C, K, eps, normalize, s);
+        case 2: return launch_simmap<T, 2>(a, b, out, M, C, K, eps, normalize, s);
+        case 3: return launch_simmap<T, 3>(a, b, out, M, C, K, eps, normalize, s);
+        case 4: return launch_simmap<T, 4>(a, b, out, M, C, K, eps, normalize, s);
+        case 5: case 6: return launch_simmap<T, 6>(a, b, out, M, C, K, eps, normalize, s);
+        default: return launch_simmap<T, 8>(a, b, out, M, C, K, eps, normalize, s);
+    }
+}
+
 template <typename T, typename TO, bool TA, bool TB, bool AL = true, int KB = 128>
 int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int BK = KB / (int)sizeof(T);
@@ -771,6 +872,17 @@ extern "C" int simseg_set_gemm_variant(int v) {
 
 namespace {
 }  // namespace
+
+extern "C" int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M, int64_t C, int64_t K, int dtype,
+                                     float eps, int normalize, void* stream) {
+    SS_CHECK(x && text && out, "patch_text_sim: null pointer");
+    SS_CHECK(M > 0 && C > 0 && C <= 256 && K > 0 && M < (1ll << 31), "patch_text_sim: need 1 <= C <= 256 (got C=%lld)", (long long)C);
+    SS_CHECK(dtype == 0 || dtype == 1, "patch_text_sim: dtype must be 0 (fp32) or 1 (bf16)");
+    const int epc = dtype == 0 ? 4 : 8;
+    SS_CHECK(K % epc == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)text % 16) == 0, "patch_text_sim: K must be a multiple of %d and the operands 16-byte aligned", epc);
+    if (dtype == 0) return dispatch_simmap<float>(x, text, out, (int)M, (int)C, (int)K, eps, normalize, (hipStream_t)stream);
+    return dispatch_simmap<bf16_t>(x, text, out, (int)M, (int)C, (int)K, eps, normalize, (hipStream_t)stream);
+}
 
 // dtype codes: 0 = fp32, 1 = bf16
 extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,

@@ -95,12 +95,14 @@ def patch_text_similarity(patch_proj, text_feat, eps=1e-12, compute_dtype=F32):
     The row normalisation is fused into the GEMM epilogue as a row scale."""
     B, N, P = patch_proj.shape
     x = patch_proj.contiguous().view(B * N, P)
-    rn = ops.row_rnorm(x, eps)
     t = text_feat.contiguous()
-    if compute_dtype == torch.bfloat16:
-        x, t = (x if x.dtype == torch.bfloat16 else ops.cast(x.float(), torch.bfloat16)), ops.cast(t.float(), torch.bfloat16)
-    else:
-        x, t = x.float(), t.float()
+    want = torch.bfloat16 if compute_dtype == torch.bfloat16 else F32
+    x = x if x.dtype == want else (ops.cast(x.float(), torch.bfloat16) if want == torch.bfloat16 else x.float())
+    t = t if t.dtype == want else (ops.cast(t.float(), torch.bfloat16) if want == torch.bfloat16 else t.float())
+    epc = 8 if want == torch.bfloat16 else 4
+    if t.shape[0] <= 256 and P % epc == 0:
+        return ops.patch_text_sim(x, t, eps).view(B, N, t.shape[0])      # fused: x is read once
+    rn = ops.row_rnorm(x, eps)                                           # > 256 classes: row scale in the GEMM epilogue
     return ops.gemm(x, t, rowscale=rn, out_dtype=F32).view(B, N, t.shape[0])
 
 

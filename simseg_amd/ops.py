@@ -176,6 +176,18 @@ def segment_mean_l2norm(x):
     return out
 
 
+def patch_text_sim(x2d, text, eps=1e-12, normalize=True):
+    """Fused K14 kernel: x2d [M,K], text [C,K] (same dtype, C <= 256) -> fp32 [M,C] cosine map."""
+    require_gpu(x2d, text)
+    if x2d.dtype != text.dtype:
+        raise TypeError("patch_text_sim: x and text must share a dtype")
+    M, K = x2d.shape
+    C = text.shape[0]
+    out = torch.empty(M, C, device=x2d.device, dtype=torch.float32)
+    call("simseg_patch_text_sim", ptr(_c(x2d)), ptr(_c(text)), ptr(out), M, C, K, dt(x2d), float(eps), int(normalize), stream())
+    return out
+
+
 def row_rnorm(x2d, eps=1e-12):
     require_gpu(x2d)
     rn = torch.empty(x2d.shape[0], device=x2d.device, dtype=torch.float32)

@@ -412,3 +412,17 @@ def test_adamw_multi_tensor_optimizer():
         o1.step(); o2.step()
     for a, b in zip(ours, ref):
         _close(a.detach(), b.detach(), 1e-5, "multi-tensor adamw")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,K", [(324, 21, 512), (1024, 171, 512), (777, 60, 512), (130, 81, 384), (4096, 256, 512), (64, 1, 128)])
+def test_patch_text_sim_fused(ops, dtype, M, C, K):
+    """Fused K14 kernel (row L2-normalise + all-class contraction) vs torch on the same inputs."""
+    x = (_rand(M, K, seed=1) * 3.0).to(dtype)
+    t = F.normalize(_rand(C, K, seed=2), dim=-1).to(dtype)
+    ref = F.normalize(x.float(), dim=-1) @ t.float().T
+    got = ops.patch_text_sim(x, t)
+    assert got.shape == (M, C)
+    _close(got, ref, 1e-5 if dtype == torch.float32 else 1e-5, f"fused sim map {M}x{C}x{K}")
+    plain = ops.patch_text_sim(x, t, normalize=False)
+    _close(plain, x.float() @ t.float().T, 1e-5, "plain contraction")
