@@ -28,6 +28,14 @@ struct AttnParams {
 };
 
 // online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
+// FAST: raw v_exp_f32 (arguments are <= 0, results in [0,1]; no denormal-range fix-up code) -- used by the bf16 kernels,
+// where the softmax VALU work, not the MFMAs, bounds the kernel
+template <bool FAST> __device__ __forceinline__ float ex2(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_exp2f(x);
+    else return exp2f(x);
+}
+
+template <bool FAST>
 __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias, int h2, float scale_log2e, float& m,
                                              float& lsum, float& alpha) {
     float mx = NEG;
@@ -42,14 +50,14 @@ __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias,
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    alpha = exp2f(m - mn);
+    alpha = ex2<FAST>(m - mn);
     m = mn;
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(s[kb][r] - mn);
+            const float p = ex2<FAST>(s[kb][r] - mn);
             s[kb][r] = p;
             ps += p;
         }
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(AttnParams p) {
             }
         }
         float alpha;
-        softmax_tile(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
+        softmax_tile<false>(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
             }
         }
         float alpha;
-        softmax_tile(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
+        softmax_tile<true>(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const float pr = exp2f(s[r] * p.scale_log2e + kb_ - lseq[qq]);
+            const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lseq[qq], 0.f));
             float keep = 1.f;
             if (p.drop_thresh) {
                 const unsigned long long idx = ((unsigned long long)blockIdx.y * T + (q0 + qq)) * T + key;
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                const float pr = exp2f(s[r] * p.scale_log2e + kbias[kk_] - lse);
+                const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kbias[kk_] - lse, 0.f));
                 float keep = 1.f;
                 if (p.drop_thresh) {
                     const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + (kv0 + kk_);

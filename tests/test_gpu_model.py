@@ -210,3 +210,30 @@ def test_class_text_embeddings_prompt_ensemble(golden, monkeypatch):
             e = ref.forward_text_project(ref.forward_text_feature(ids[sl], mask[sl]), mask[sl]).mean(dim=0)
             want.append(e / e.norm())
     assert _maxerr(got, torch.stack(want)) < 1e-3
+
+
+def test_trainer_iteration_and_checkpoint_roundtrip(golden, tmp_path):
+    """A few reference-style training iterations (stateless LR, autocast forward, AdamW) reduce the loss on a fixed batch;
+    the checkpoint has the reference's layout and restores model + optimizer exactly."""
+    from simseg_amd.trainer import Trainer
+    g = golden("clip_train_ws1")
+    m = _build(golden, ["epoch=1", "optim.lr.init=1e-3"])
+    cfg = m.cfg
+    tr = Trainer(m, cfg, steps_per_epoch=40)
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    m.eval()                               # deterministic (no dropout) so that the resume check below is exact
+    losses = [float(tr.train_step(batch)["loss"]) for _ in range(12)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 1e-3 * (0.1 + 0.9 * 0.5 * (1 + np.cos(np.pi * (11 - 1) / 39)))) < 1e-9
+    ck = tr.checkpoint()
+    assert set(ck) == {"state_dict", "optimizer", "meta", "scaler"} and ck["meta"]["step"] == 12
+    assert "image_encoder.model.model.blocks.0.attn.qkv.weight" in ck["state_dict"] and "loss.temperature" in ck["state_dict"]
+    path = tmp_path / "step_checkpoint.pth"
+    torch.save(ck, path)
+    nxt = float(tr.train_step(batch)["loss"])
+    m2 = _build(golden, ["epoch=1", "optim.lr.init=1e-3"])
+    m2.eval()
+    tr2 = Trainer(m2, m2.cfg, steps_per_epoch=40)
+    tr2.load_checkpoint(torch.load(path, weights_only=False))
+    assert tr2.step == 12
+    assert abs(float(tr2.train_step(batch)["loss"]) - nxt) < 1e-6

@@ -115,3 +115,22 @@ def test_get_dist_state_dict_and_key_helpers():
         ENV.dist_mode = old
     assert list(filter_state(sd, remove_prefixes=("loss.",))) == ["image_encoder.model.model.cls_token"]
     assert list(convert_keys(sd, [["image_encoder.", "img."]])) == ["img.model.model.cls_token", "loss.temperature"]
+
+
+def test_lr_schedules_match_reference_formulas():
+    """Stateless LR multipliers (simseg/core/optimizer/lr_scheduler.py) incl. the YAML's cosine_schedule_with_warmup_min_lr_scale."""
+    import math
+    from simseg_amd.trainer import lr_multiplier
+    kw = dict(num_warmup_steps=25, num_training_steps=1000, num_cycles=0.5, min_lr_scale=0.1)
+    name = "cosine_schedule_with_warmup_min_lr_scale"
+    assert lr_multiplier(name, 0, **kw) == 0.0
+    assert abs(lr_multiplier(name, 10, **kw) - 10 / 25) < 1e-12
+    assert abs(lr_multiplier(name, 25, **kw) - 1.0) < 1e-12
+    for step in (100, 512, 999):
+        prog = (step - 25) / (1000 - 25)
+        want = 0.1 + 0.9 * 0.5 * (1 + math.cos(math.pi * prog))
+        assert abs(lr_multiplier(name, step, **kw) - want) < 1e-12
+    assert abs(lr_multiplier(name, 1000, **kw) - 0.1) < 1e-12
+    assert lr_multiplier("constant_schedule", 123) == 1.0
+    assert abs(lr_multiplier("linear_schedule_with_warmup", 512, num_warmup_steps=24, num_training_steps=1000) - (1 - 488 / 976)) < 1e-12
+    assert lr_multiplier("cosine_schedule_with_warmup", 1000, num_warmup_steps=0, num_training_steps=1000) == 0.0
