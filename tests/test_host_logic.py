@@ -134,3 +134,25 @@ def test_lr_schedules_match_reference_formulas():
     assert lr_multiplier("constant_schedule", 123) == 1.0
     assert abs(lr_multiplier("linear_schedule_with_warmup", 512, num_warmup_steps=24, num_training_steps=1000) - (1 - 488 / 976)) < 1e-12
     assert lr_multiplier("cosine_schedule_with_warmup", 1000, num_warmup_steps=0, num_training_steps=1000) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tools"), reason="reference checkout not present (GPU box)")
+def test_reference_tools_import_against_this_package(monkeypatch):
+    """Every `simseg.*` name the reference's unmodified eval tools import resolves to this repo's package
+    (tools/seg_evaluation.py:19-28, tools/retrieval_evaluation.py:13-22).  cv2 / pydensecrf are third-party CPU
+    post-processing libraries absent from the image: stubbed, never called."""
+    import importlib.util
+    import sys
+    import types
+    for name in ("cv2", "pydensecrf", "pydensecrf.densecrf"):
+        if name not in sys.modules:
+            monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["pydensecrf"].densecrf = sys.modules["pydensecrf.densecrf"]
+    import simseg
+    assert simseg.__file__.startswith(REPO)
+    for tool in ("seg_evaluation", "retrieval_evaluation"):
+        spec = importlib.util.spec_from_file_location(f"_ref_tool_{tool}", f"/root/reference/tools/{tool}.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)              # runs the tool's imports and definitions, not its main()
+        assert hasattr(mod, "evaluate_benchmark") and hasattr(mod, "main")
+    assert sys.modules["simseg.models"].__file__.startswith(REPO)
