@@ -96,7 +96,7 @@ def cpu_baseline(img, L, budget_s=20.0):
             "sample": f"{n} fwd+bwd+AdamW steps of {B} pairs (ViT-B/16 @{img}, BERT-base L={L}) with the torch-fp32 oracle"}
 
 
-def seg_eval_bench(dev, world, dtype, windows=16, steps=4, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
+def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
     """Zero-shot segmentation GPU stage (BASELINE configs[3] shape): ViT-B on 512x512 windows -> projection -> LoDA pooled
     embedding + dense patch x class-text similarity map for all `classes` (tools/seg_evaluation.py:99-143 without the CPU
     CRF stage).  Independent windows: sharded over ranks with no collective.  Returns windows/s over all ranks."""
@@ -138,6 +138,26 @@ def seg_eval_bench(dev, world, dtype, windows=16, steps=4, img=512, classes=171,
     return {"windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
             "classes": classes, "windows_per_step_per_gpu": windows, "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
             "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
+
+
+def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
+    """BASELINE configs[4] shape: R@1/5/10 in both directions over the full 5k x 25k similarity matrix (fp32 MFMA GEMM +
+    first-match-rank kernel instead of the reference's argsort + int64 gid gather, hooks/utils.py:36-42)."""
+    from simseg_amd.heads import retrieval_recalls
+    g = torch.Generator().manual_seed(5)
+    img = torch.nn.functional.normalize(torch.randn(m, d, generator=g), dim=-1).to(dev)
+    txt = torch.nn.functional.normalize(img.repeat_interleave(n // m, 0) + 0.08 * torch.randn(n, d, generator=g).to(dev), dim=-1)
+    gi, gt = torch.arange(m, device=dev), torch.arange(n, device=dev) // (n // m)
+    retrieval_recalls(img, gi, txt, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        a = retrieval_recalls(img, gi, txt, gt)
+        b = retrieval_recalls(txt, gt, img, gi)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"shape": f"{m}x{n}x{d}, both directions", "ms_per_eval": round(dt * 1e3, 3), "similarities_per_s": round(2.0 * m * n / dt, 1),
+            "gemm_tflops_fp32": round(2 * 2.0 * m * n * d / dt / 1e12, 1), "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
 
 
 def main():
@@ -229,6 +249,7 @@ def main():
         seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16")}
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"seg eval stage: {seg}")
+    retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
 
     if rank == 0:
         n_patches = (args.img // 16) ** 2
@@ -267,6 +288,7 @@ def main():
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4)},
             "seg_eval": seg,
+            "retrieval_eval": retr,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

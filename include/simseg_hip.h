@@ -44,7 +44,8 @@ int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int
 int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M, int64_t C, int64_t K, int dtype, float eps,
                           int normalize, void* stream);
 
-/* Kernel selection for benchmarking: 0 auto, 1 128x128 register-staged, 2 256x256 BK64x2, 3 256x256 BK32x4 ring. */
+/* Kernel selection for benchmarking / tests: 0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS kernel
+ * (+100: debug, epilogue skipped and a cycle-counter timeline written to C by tools/dbg_gemm_timeline.py). */
 int simseg_set_gemm_variant(int v);
 
 /* LayerNorm over the last dim of x[rows,D] (fp32 residual stream) -> y (out_dtype) and optionally a bf16 copy.

@@ -723,123 +723,10 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
 }
 
 
-// =================================================================================================================
-// Persistent variant of the 256x256 direct-to-LDS kernel: one block per CU walks a contiguous (per XCD) list of tiles.
-// The first K-slab of the NEXT tile is issued before the current tile's epilogue, so its fetch latency is hidden by
-// the epilogue and the epilogue's stores drain underneath the next tile's main loop -- the two fixed costs that make
-// the one-shot 256x256 kernel lose to the 128x128 kernel at K = 768.  The epilogue scratch is the stage that has just
-// been consumed (plus 8 KiB of padding on that side); the other stage is receiving the prefetched slab.
-// =================================================================================================================
-template <typename TO, bool TA, bool TB>
-__global__ __launch_bounds__(LTHREADS, 2) void gemm_persist_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    constexpr int BKE = 64, TM = 256, TN = 256, WN_ = 4;
-    constexpr int SLAB = TM * BKE * 2, STAGE = 2 * SLAB;        // 32 KiB, 64 KiB
-    constexpr int PAD = 8192;
-    static_assert(STAGE + PAD >= 8 * EP_WAVE_FLOATS * 4, "one stage + pad holds the epilogue scratch of 8 waves");
-    char* const stage0 = lds_raw + PAD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN_, wn = wave % WN_;
-    const int tiles_n = (p.N + TN - 1) / TN;
-    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
-    const int nk = p.K / BKE;
-    const bf16_t* A = static_cast<const bf16_t*>(p.A);
-    const bf16_t* B = static_cast<const bf16_t*>(p.B);
-    const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
-
-    // tile list of this block: XCD x = blockIdx % 8 owns tiles [lo, hi); its blocks take them round-robin
-    const int nxcd = 8, x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const int q8 = tiles / nxcd, r8 = tiles % nxcd;
-    const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
-    const int hi = lo + (x < r8 ? q8 + 1 : q8);
-
-    int t = lo + j;
-    if (t >= hi) return;
-    int st = 0;
-    {
-        const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
-        glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, 0, stage0, wave, lane);
-        glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, 0, stage0 + SLAB, wave, lane);
-    }
-    for (; t < hi; t += per) {
-        const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
-        const int tn = t + per;
-        f32x16 acc[4][2];
-        {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = zero;
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            char* nxt = stage0 + (st ^ 1) * STAGE;
-            if (kt + 1 < nk) {
-                glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, (kt + 1) * BKE, nxt, wave, lane);
-                glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, (kt + 1) * BKE, nxt + SLAB, wave, lane);
-            } else if (tn < hi) {       // cross-tile prefetch: the next tile's first slab
-                const int m1 = (tn / tiles_n) * TM, n1 = (tn % tiles_n) * TN;
-                glds_slab<BKE, TA, TM>(A, p.lda, m1, p.M, 0, nxt, wave, lane);
-                glds_slab<BKE, TB, TN>(B, p.ldb, n1, p.N, 0, nxt + SLAB, wave, lane);
-            }
-            const char* sa = stage0 + st * STAGE;
-            const char* sb = sa + SLAB;
-#pragma unroll
-            for (int kk = 0; kk < BKE / 16; ++kk) {
-                u32x4 fa[4], fb[2];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) fb[jj] = read_frag_l<BKE, TB, TN>(sb, wn * 64 + jj * 32, kk, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = read_frag_l<BKE, TA, TM>(sa, wm * 128 + i * 32, kk, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) mma<bf16_t>(acc[i][jj], fa[i], fb[jj]);
-            }
-            st ^= 1;
-        }
-        // the stage consumed last (st ^ 1) is free once every wave has passed this barrier; the other one is being filled
-        __builtin_amdgcn_s_barrier();
-        char* scratch = (st ^ 1) == 0 ? lds_raw : stage0 + STAGE;          // [pad | stage0]  or  [stage1 | pad]
-        float* wlds = reinterpret_cast<float*>(scratch) + wave * EP_WAVE_FLOATS;
-        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            f32x16 l = acc[0][0], r = acc[0][1];
-#pragma unroll
-            for (int ii = 1; ii < 4; ++ii)
-                if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
-            epilogue_block<TO>(p, l, r, wlds, m0 + wm * 128 + i * 32, n0 + wn * 64, lane, false, vec_ok, cs);
-        }
-        flush_colsum(p, cs, n0 + wn * 64, lane);
-    }
-}
-
-template <typename TO, bool TA, bool TB>
-int launch_persist(const GemmParams& p, hipStream_t stream) {
-    constexpr int SMEM = 2 * 65536 + 2 * 8192;
-    static bool configured = false;
-    auto kern = gemm_persist_kernel<TO, TA, TB>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
-        configured = true;
-    }
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    int grid = tiles < 256 ? ((tiles + 7) / 8) * 8 : 256;      // a multiple of 8 blocks: the same count on every XCD
-    GemmParams q = p;
-    q.ksplit = p.K / 64; q.nsplit = 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(LTHREADS), SMEM, stream, q);
-    SS_LAUNCH_CHECK("simseg_gemm(persistent)");
-    return 0;
-}
-
 int g_gemm_debug_skip_epilogue = 0;
-// variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 BK64 x2 stages, 3 = 256x256 BK32 x4-stage ring,
-//          4 = 256x128 BK32 x3-stage ring at 2 blocks/CU
+// variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
+// space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
+// 128x128 with BK=128, and a persistent 256x256 kernel with cross-tile prefetch.
 int g_gemm_variant = 0;
 
 template <typename TO, bool TA, bool TB>
@@ -855,10 +742,6 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 256) ? 2 : 1;
     if (!big_ok) v = 1;
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
-    if (v == 3) return launch_large<TO, TA, TB, 32, 4, 256, 256, 2, 4, 2>(p, splitk, s);
-    if (v == 4) return launch_large<TO, TA, TB, 32, 3, 256, 128, 4, 2, 4>(p, splitk, s);
-    if (v == 5 && aligned && p.K % 128 == 0) return launch<bf16_t, TO, TA, TB, true, 256>(p, splitk, s);
-    if (v == 6 && splitk <= 1) return launch_persist<TO, TA, TB>(p, s);
     return launch<bf16_t, TO, TA, TB>(p, splitk, s);
 }
 

@@ -22,7 +22,7 @@ def _c(t):
 
 
 def set_gemm_variant(v):
-    """0 auto, 1 128x128 register-staged kernel, 2 256x256 BK64 x2 stages, 3 256x256 BK32 x4-stage ring."""
+    """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS kernel (tests / benchmarks only)."""
     call("simseg_set_gemm_variant", int(v))
 
 

@@ -91,7 +91,7 @@ def test_gemm_bf16_layouts(ops, ta, tb, M, N, K):
     _close(ops.gemm(a, b, trans_a=ta, trans_b=tb), ref, 1e-2, f"bf16 ta={ta} tb={tb} bf16 out")
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 520, 192), (256, 136, 64), (2048, 768, 768), (16640, 768, 192)])
 def test_gemm_bf16_large_tile_kernel(ops, variant, ta, tb, M, N, K):
@@ -104,10 +104,9 @@ def test_gemm_bf16_large_tile_kernel(ops, variant, ta, tb, M, N, K):
         _close(ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32), ref, 1e-5, f"large v{variant} ta={ta} tb={tb}")
         bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
         _close(ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32), ref + bias + res, 1e-5, "large + epilogue")
-        if variant != 6:      # the persistent kernel has no split-K form
-            acc = torch.zeros(M, N, device="cuda")
-            ops.gemm(a, b, trans_a=ta, trans_b=tb, out=acc, accumulate=True, splitk=3)
-            _close(acc, ref, 2e-5, "large split-K")
+        acc = torch.zeros(M, N, device="cuda")
+        ops.gemm(a, b, trans_a=ta, trans_b=tb, out=acc, accumulate=True, splitk=3)
+        _close(acc, ref, 2e-5, "large split-K")
     finally:
         ops.set_gemm_variant(0)
 
