@@ -650,7 +650,8 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     for (int kt = kt0; kt < kt1; ++kt) {
         // slab kt must have landed; up to NSTAGE-2 younger slabs may stay in flight
         const int ahead = min(NSTAGE - 2, kt1 - 1 - kt);
-        if (NSTAGE >= 4 && ahead >= 2) wait_vm<2 * LPS>();
+        if (NSTAGE >= 5 && ahead >= 3) wait_vm<3 * LPS>();
+        else if (NSTAGE >= 4 && ahead >= 2) wait_vm<2 * LPS>();
         else if (NSTAGE >= 3 && ahead >= 1) wait_vm<LPS>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
@@ -723,10 +724,12 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
 }
 
 
+
 int g_gemm_debug_skip_epilogue = 0;
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
-// 128x128 with BK=128, and a persistent 256x256 kernel with cross-tile prefetch.
+// 128x128 with BK=128, a persistent 256x256 kernel with cross-tile prefetch, deeper BK32 rings (4 and 5 stages) and a
+// two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
 int g_gemm_variant = 0;
 
 template <typename TO, bool TA, bool TB>
