@@ -268,7 +268,8 @@ def main():
             pass
         kdesc = {"_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)", "": "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)"}["_L" if dom.endswith("_L") else ""]
         out = {
-            "metric": "image-text pairs/sec (train)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world,
+            "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",
+            "value_is": "training image-text pairs/s over all ranks; the zero-shot-seg eval rate is reported in seg_eval", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"ViT-B/16 + BERT-base contrastive pretrain step (fwd + global InfoNCE + bwd + AdamW), "

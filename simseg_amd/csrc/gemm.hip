@@ -460,27 +460,30 @@ __global__ __launch_bounds__(NTHREADS) void simmap_kernel(const T* __restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                // A operand = class rows (MFMA rows), B operand = patch rows (MFMA columns): the accumulator then holds one
-                // PATCH per lane and 16 classes per lane, so the row scale is lane-local and a lane's 4-register groups are
-                // 4 consecutive classes of one output row
+                // A operand = patch rows (MFMA rows), B operand = class rows (MFMA columns): a lane owns ONE class column, so
+                // every store instruction writes 32 consecutive classes of a row (128-byte runs)
                 const u32x4 fb = read_frag<false, KB>(ldsB, j * 32, kk, lane);
-                mma<T>(acc[j], fb, fa);
+                mma<T>(acc[j], fa, fb);
             }
         }
         __syncthreads();
     }
     ss += __shfl_xor(ss, 32, 64);
-    const float rn = normalize ? 1.0f / fmaxf(sqrtf(ss), eps) : 1.0f;
-    const int row = m0 + wave * 32 + (lane & 31);
-    if (row < M) {
+    const float rn = normalize ? 1.0f / fmaxf(sqrtf(ss), eps) : 1.0f;       // lane l (either half) holds the scale of patch row l % 32
+    float rnv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rnv[r] = __shfl(rn, (r & 3) + 8 * (r >> 2) + 4 * h2, 64);
+    const int cl = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (row >= M) continue;
         float* orow = out + (long)row * C;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                if (c < C) orow[c] = acc[j][r] * rn;
-            }
+        for (int j = 0; j < NT; ++j) {
+            const int c = j * 32 + cl;
+            if (c < C) orow[c] = acc[j][r] * rnv[r];
+        }
     }
 }
 
