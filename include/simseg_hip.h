@@ -141,6 +141,9 @@ int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void
 /* g[i] = keep(seed, i) ? g[i] / (1-p) : 0 -- regenerates the forward dropout mask of simseg_gemm for the backward. */
 int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream);
 
+/* debug: bf16 attention forward that also writes a 5-entry cycle-counter timeline of block (0,0) to dbg (tools/dbg_attn_timeline.py). */
+int simseg_debug_attention_timeline(const void* qkv, void* out, float* lse, void* dbg, int64_t B, int64_t T, int64_t H, void* stream);
+
 /* hardware probe used by tests: lane/element map of ds_read_b64_tr_b16. */
 int simseg_debug_tr16_probe(int* out_dev, void* stream);
 

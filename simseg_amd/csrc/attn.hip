@@ -241,6 +241,9 @@ __device__ __forceinline__ void kbias_fill(float* kbias, const long* mask, int b
     }
 }
 
+// DROP: attention_probs dropout compiled in (BERT training only).  DBG: cycle-counter timeline written through p.delta
+// (tools/dbg_attn_timeline.py); the production instantiations carry neither.
+template <bool DROP, bool DBG>
 __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * VP16 + KT * 4];
     char* ldsK = lds;
@@ -271,33 +274,53 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const int HD = p.H * 64;
 
+    unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long dt0 = __builtin_readcyclecounter();
+    const unsigned long long dbg_start = dt0;
     kv_direct(base, RS, HD, 0, T, ldsK, ldsV, VP16, tid, nthr);
     kbias_fill(kbias, p.mask, b, 0, T, tid);
     __syncthreads();
+    // Q must be known-landed before the loop: the prefetch loads inside it sit under divergent guards, so a later wait on
+    // Q would have to be vmcnt(0) and would serialise the prefetch with the first MFMAs of every tile
+    asm volatile("" ::"v"(qr[0]), "v"(qr[1]), "v"(qr[2]), "v"(qr[3]));
+    dbg[0] = __builtin_readcyclecounter() - dt0;
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
         const bool more = kv0 + KT < T;
         KVRegs nxt;
+        dt0 = __builtin_readcyclecounter();
         if (more) kv_fetch(nxt, base, RS, HD, kv0 + KT, T, tid, nthr);     // in flight during this tile's MFMAs
 
+        // all eight K fragments are requested before the first MFMA (one LDS round trip per tile instead of one per
+        // MFMA), and the two key blocks' accumulation chains are interleaved so no MFMA waits on its predecessor
+        const bool two = kv0 + 32 < T;              // else the second 32-key block is all padding (its P is exactly 0)
+        bf16x8 kf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i] = ld_bf16x8(ldsK + ((i >> 2) * 32 + ql) * KP16 + (2 * (i & 3) + h2) * 16);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-            if (kv0 + kb * 32 >= T) continue;       // whole 32-key block is padding (kbias = NEG makes its P exactly 0)
+        if (two) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 a = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qr[kk], s[kb], 0, 0, 0);
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
         }
         float alpha;
+        if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[1] += t1 - dt0; dt0 = t1; }
         softmax_tile<true>(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        if (p.drop_thresh) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
+        if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[2] += t1 - dt0; dt0 = t1; }
+        if (DROP) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -307,29 +330,35 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
                     s[kb][r] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
                 }
         }
+        {   // same for V: all transposed fragments first, then eight MFMAs alternating between the two d-blocks
+            bf16x8 vf[8];
+            const char* vbase = ldsV + (4 * h2 + (a16 >> 2)) * VP16 + (16 * g16 + 4 * (a16 & 3)) * 2;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kv0 + kb * 32 >= T) continue;
+            for (int i = 0; i < 8; ++i)       // i = kb*4 + s2*2 + db
+                vf[i] = tr_frag(vbase + ((i >> 2) * 32 + 16 * ((i >> 1) & 1)) * VP16 + (i & 1) * 64, 8 * VP16);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !two) break;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
-                const int k0 = kb * 32 + 16 * s2 + 4 * h2;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* vp = ldsV + (k0 + (a16 >> 2)) * VP16 + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
-                    const bf16x8 vf = tr_frag(vp, 8 * VP16);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
                 }
             }
         }
+        if (DBG) { asm volatile("" ::"v"(o[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[3] += t1 - dt0; dt0 = t1; }
         if (more) {
             __syncthreads();
             kv_commit(nxt, ldsK, ldsV, VP16, tid, nthr);
             kbias_fill(kbias, p.mask, b, kv0 + KT, T, tid);
             __syncthreads();
         }
+        if (DBG) { unsigned long long t1 = __builtin_readcyclecounter(); dbg[4] += t1 - dt0; dt0 = t1; }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
@@ -344,6 +373,21 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
                 *reinterpret_cast<bf16x4*>(orow + d) = v;
             }
         if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+    }
+    if (DBG && tid == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.delta));
+        const unsigned long long tend = __builtin_readcyclecounter();
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            for (int i = 0; i < 5; ++i) d[i] = dbg[i];
+            d[5] = tend - dbg_start;
+            d[6] = dbg_start;
+        }
+        // per-block record: start, end, HW_ID (wave/simd/cu/se), XCC_ID
+        const long blin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        d[8 + blin * 4 + 0] = dbg_start;
+        d[8 + blin * 4 + 1] = tend;
+        d[8 + blin * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        d[8 + blin * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
     }
 }
 
@@ -675,8 +719,23 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     if (dtype == 0)
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+        if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_fwd");
+    return 0;
+}
+
+// debug: forward with a cycle-counter timeline of block (0,0) / thread 0 written to dbg[0..4] (5 x u64):
+// {first tile staging, S = K.Q^T, softmax + rescale, P.V, next-tile commit + barriers}, summed over the K/V tiles
+extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float* lse, void* dbg, int64_t B, int64_t T, int64_t H, void* stream) {
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, 0.125f, 0, 0.f)) return rc;
+    p.out = out; p.lse = lse; p.delta = reinterpret_cast<const float*>(dbg);
+    const int q32 = (int)((T + 31) / 32);
+    const int nw = attn_waves_per_block(q32);
+    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+    SS_LAUNCH_CHECK("attention_timeline");
     return 0;
 }
 

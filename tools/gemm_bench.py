@@ -24,6 +24,27 @@ SHAPES = {
 }
 
 
+def run_vendor(kind, M, N, K, iters):
+    """Yardstick only (never used by the product path): the vendor BLAS through torch.matmul on the same operands/layouts."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    ta, tb = kind == "tn", kind in ("nn", "tn")
+    a = torch.randn((K, M) if ta else (M, K), device=dev, generator=g).bfloat16()
+    b = torch.randn((K, N) if tb else (N, K), device=dev, generator=g).bfloat16()
+    A = a.t() if ta else a
+    Bm = b if tb else b.t()
+    for _ in range(3):
+        torch.matmul(A, Bm)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(A, Bm)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
 def run(kind, M, N, K, iters, out_f32=False):
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -55,13 +76,14 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--vendor", action="store_true", help="time torch.matmul (vendor BLAS) instead, as a yardstick")
     args = ap.parse_args()
     ops.set_gemm_variant(args.variant)
     tot_ms = tot_fl = 0.0
     for kind, M, N, K in SHAPES[args.shapes]:
         if args.only and kind != args.only:
             continue
-        ms, tf = run(kind, M, N, K, args.iters)
+        ms, tf = (run_vendor if args.vendor else run)(kind, M, N, K, args.iters)
         tot_ms += ms; tot_fl += 2.0 * M * N * K
         print(f"{kind} M={M:6d} N={N:5d} K={K:6d}  {ms:8.3f} ms  {tf:8.1f} TFLOP/s", flush=True)
     print(f"sum {tot_ms:.3f} ms  -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
