@@ -141,6 +141,28 @@ int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void
 /* g[i] = keep(seed, i) ? g[i] / (1-p) : 0 -- regenerates the forward dropout mask of simseg_gemm for the backward. */
 int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream);
 
+/* ---- zero-shot segmentation post-processing (tools/seg_evaluation.py:112-170) ---------------------------------
+ * scores [B,C] = pooled . text^T.  Top `top_cls_num` classes (:121), threshold = mean + unbiased std of those (:122-123); the
+ * first `ncand` (reference: 5, :128-130) become candidates.  cand_idx[b,i] = class index, or -1 where the reference skips the
+ * slot (class 0 / 255 :132-133, or score < threshold :145-146); cand_score[b,i] = its score; threshold[b] optional. */
+int simseg_seg_select(const float* scores, int* cand_idx, float* cand_score, float* threshold, int64_t B, int64_t C,
+                      int64_t top_cls_num, int64_t ncand, void* stream);
+/* sim [B, n*n, C] fp32 (simseg_patch_text_sim).  Per valid candidate: its column, min-max normalised (:148-149) -> prob
+ * [B,ncand,n*n] (optional, the DenseCRF unary input) and the binary map prob > 0.5 scaled to 255 (what dense_crf :30-54 returns
+ * with its pairwise terms off), nearest-upsampled x16 (:137) -> mask [B,ncand,16n,16n] bytes.  Invalid slots are not written. */
+int simseg_seg_masks(const float* sim, const int* cand_idx, float* prob, void* mask, int64_t B, int64_t n, int64_t C, int64_t ncand,
+                     void* stream);
+/* cv2.dilate / cv2.erode with a 7x7 ones kernel, ONE iteration (the third positional argument in :156-157 is `dst`, not
+ * `iterations`), default border (never wins) on byte images [M,H,W]; erode = 0 dilate, 1 erode.  out must not alias in. */
+int simseg_morph7(const void* in, void* out, int64_t M, int64_t H, int64_t W, int erode, void* stream);
+/* masks [B,ncand,Hm,Wm] bytes -> nearest resize to (H,W) (cv2.INTER_NEAREST :159) -> temp_pred[class] = mask * score (:160) ->
+ * argmax over classes (:163; first maximum, class 0 when nothing is positive) -> pred [B,H,W] int32 (optional) and
+ * hist [3,C] uint64 += {intersect, pred area, label area} over pixels whose label != ignore_index (utils/metrics.py:60-74).
+ * labels [B,H,W] bytes. */
+int simseg_seg_predict(const void* masks, const int* cand_idx, const float* cand_score, const void* labels, int* pred, void* hist,
+                       int64_t B, int64_t ncand, int64_t Hm, int64_t Wm, int64_t H, int64_t W, int64_t C, int64_t ignore_index,
+                       void* stream);
+
 /* debug: bf16 attention forward that also writes a 5-entry cycle-counter timeline of block (0,0) to dbg (tools/dbg_attn_timeline.py). */
 int simseg_debug_attention_timeline(const void* qkv, void* out, float* lse, void* dbg, int64_t B, int64_t T, int64_t H, void* stream);
 

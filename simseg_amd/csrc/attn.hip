@@ -419,19 +419,29 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 constexpr int QT = 32;   // queries per LDS tile in the dK/dV kernel
 constexpr int QP = 144;  // pitch of the Q / dO tiles (read both k-contiguous and transposed)
+constexpr int QBUF = 2 * QT * QP + 2 * QT * 4;   // one stage: Q tile, dO tile, lse[32], delta[32]
 
+__device__ __forceinline__ void store_bf16x4(bf16_t* dst, float a, float b, float c, float d) {
+    const bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<bf16x4*>(dst) = v;
+}
+
+// Schedule notes (both backward kernels, same as the forward): every LDS fragment a group of MFMAs needs is requested
+// before the first MFMA of the group (one LDS round trip per group, not one per MFMA); the two accumulators of a group
+// alternate so no MFMA waits on its predecessor; the gradient products are formed TRANSPOSED (A = transposed LDS
+// fragment, B = the probabilities), which leaves each lane with four consecutive d of its own key / query row: 8-byte
+// stores instead of 2-byte ones.  The Q/dO stage is double buffered: one barrier per 32-query tile.
+template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * QT * QP + 2 * QT * 4];
-    char* ldsQ = lds;
-    char* ldsG = lds + QT * QP;                         // dO tile
-    float* lseq = reinterpret_cast<float*>(lds + 2 * QT * QP);
-    float* delq = lseq + QT;
+    __shared__ __attribute__((aligned(16))) char lds[2 * QBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, kl = lane & 31;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int T = p.T;
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const float* lse_g = p.lse + ((long)b * p.H + h) * T;
+    const float* del_g = p.delta + ((long)b * p.H + h) * T;
     const int nthr = blockDim.x;
     const int key = blockIdx.x * (nthr >> 1) + wave * 32 + kl;
     const bool kvalid = key < T;
@@ -456,119 +466,159 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const float scale = p.scale_log2e * 0.6931471805599453f;
 
-    // Q / dO tiles of 32 queries: tile 0 directly, later tiles prefetched into registers during the previous tile's MFMAs
-    // (more than one tile means T > 32, i.e. >= 2 waves, so two 16-byte pieces per thread cover the 256 pieces)
-    auto qg_fetch = [&](int q0, u32x4 (&rq)[2], u32x4 (&rg)[2]) {
+    // Q / dO tiles of 32 queries: fetched into registers during the previous tile's MFMAs, written to the other stage.
+    // 256 16-byte pieces per operand tile; a block has >= 1 wave, so up to 4 pieces per thread (2 when nthr >= 128).
+    const int qq_ = tid >> 3, c_ = tid & 7;              // piece i of this thread: query qq_ + i * (nthr / 8), chunk c_
+    const int qstep = nthr >> 3;
+    u32x4 nq[2], ng[2];
+    float nl = 1e30f, nd = 0.f;
+    auto qg_fetch = [&](int q0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * nthr;
+            const int qq = qq_ + i * qstep;
             u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
-            if (idx < QT * 8) {
-                const int qq = idx >> 3, c = idx & 7;
-                if (q0 + qq < T) {
-                    qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c * 8);
-                    gv = *reinterpret_cast<const u32x4*>(gbase + (long)(q0 + qq) * OS + c * 8);
-                }
+            if (qq < QT && q0 + qq < T) {
+                qv = *reinterpret_cast<const u32x4*>(base + (long)(q0 + qq) * RS + c_ * 8);
+                gv = *reinterpret_cast<const u32x4*>(gbase + (long)(q0 + qq) * OS + c_ * 8);
             }
-            rq[i] = qv; rg[i] = gv;
-        }
-    };
-    auto qg_commit = [&](int q0, const u32x4 (&rq)[2], const u32x4 (&rg)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * nthr;
-            if (idx < QT * 8) {
-                const int qq = idx >> 3, c = idx & 7;
-                *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = rq[i];
-                *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = rg[i];
-            }
+            nq[i] = qv; ng[i] = gv;
         }
         if (tid < QT) {
             const bool v = q0 + tid < T;
-            lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + q0 + tid] : 1e30f;   // -> P = 0 for padded queries
-            delq[tid] = v ? p.delta[((long)b * p.H + h) * T + q0 + tid] : 0.f;
+            nl = v ? lse_g[q0 + tid] : 1e30f;            // -> P = 0 for padded queries
+            nd = v ? del_g[q0 + tid] : 0.f;
         }
     };
-    for (int idx = tid; idx < QT * 8; idx += nthr) {   // tile 0: 32 queries x 8 chunks for Q and dO
-        const int qq = idx >> 3, c = idx & 7;
-        u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
-        if (qq < T) {
-            qv = *reinterpret_cast<const u32x4*>(base + (long)qq * RS + c * 8);
-            gv = *reinterpret_cast<const u32x4*>(gbase + (long)qq * OS + c * 8);
+    auto qg_commit = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qq = qq_ + i * qstep;
+            if (qq < QT) {
+                *reinterpret_cast<u32x4*>(st + qq * QP + c_ * 16) = nq[i];
+                *reinterpret_cast<u32x4*>(st + QT * QP + qq * QP + c_ * 16) = ng[i];
+            }
         }
-        *reinterpret_cast<u32x4*>(ldsQ + qq * QP + c * 16) = qv;
-        *reinterpret_cast<u32x4*>(ldsG + qq * QP + c * 16) = gv;
-    }
-    if (tid < QT) {
-        const bool v = tid < T;
-        lseq[tid] = v ? p.lse[((long)b * p.H + h) * T + tid] : 1e30f;
-        delq[tid] = v ? p.delta[((long)b * p.H + h) * T + tid] : 0.f;
+        if (tid < QT) {
+            float* f = reinterpret_cast<float*>(st + 2 * QT * QP);
+            f[tid] = nl; f[QT + tid] = nd;
+        }
+    };
+    if (nthr >= 128) {
+        qg_fetch(0);
+        qg_commit(lds);
+    } else {                                              // single-wave block (T <= 32): four pieces per thread
+        for (int idx = tid; idx < QT * 8; idx += nthr) {
+            const int qq = idx >> 3, c = idx & 7;
+            u32x4 qv = {0u, 0u, 0u, 0u}, gv = qv;
+            if (qq < T) {
+                qv = *reinterpret_cast<const u32x4*>(base + (long)qq * RS + c * 8);
+                gv = *reinterpret_cast<const u32x4*>(gbase + (long)qq * OS + c * 8);
+            }
+            *reinterpret_cast<u32x4*>(lds + qq * QP + c * 16) = qv;
+            *reinterpret_cast<u32x4*>(lds + QT * QP + qq * QP + c * 16) = gv;
+        }
+        if (tid < QT) {
+            float* f = reinterpret_cast<float*>(lds + 2 * QT * QP);
+            f[tid] = tid < T ? lse_g[tid] : 1e30f;
+            f[QT + tid] = tid < T ? del_g[tid] : 0.f;
+        }
     }
     __syncthreads();
+    int cur = 0;
     for (int q0 = 0; q0 < T; q0 += QT) {
-        const bool more = q0 + QT < T;
-        u32x4 nq[2], ng[2];
-        if (more) qg_fetch(q0 + QT, nq, ng);
+        const bool more = q0 + QT < T;                    // more than one tile implies T > 32, i.e. nthr >= 128
+        if (more) qg_fetch(q0 + QT);
+        const char* cq = lds + cur * QBUF;
+        const char* cg = cq + QT * QP;
+        const float* cl = reinterpret_cast<const float*>(cq + 2 * QT * QP);
         // S[q][key], dP[q][key]: MFMA rows = queries (A from LDS), columns = keys (B = this lane's K / V row)
+        bf16x8 aq[4], ag[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            aq[kk] = ld_bf16x8(cq + kl * QP + (2 * kk + h2) * 16);
+            ag[kk] = ld_bf16x8(cg + kl * QP + (2 * kk + h2) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 aq = ld_bf16x8(ldsQ + kl * QP + (2 * kk + h2) * 16);
-            const bf16x8 ag = ld_bf16x8(ldsG + kl * QP + (2 * kk + h2) * 16);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kr[kk], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vr[kk], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
         }
+        // requested while the MFMAs run: lse / delta of this lane's 16 query rows, and the transposed dO / Q fragments
+        float4 l4[4], d4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            l4[j] = *reinterpret_cast<const float4*>(cl + 8 * j + 4 * h2);
+            d4[j] = *reinterpret_cast<const float4*>(cl + QT + 8 * j + 4 * h2);
+        }
+        bf16x8 gf[4], qf[4];                              // index s2 * 2 + db
+        auto load_tr = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = (16 * (i >> 1) + 4 * h2 + (a16 >> 2)) * QP + ((i & 1) * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
+                gf[i] = tr_frag(cg + off, 8 * QP);        // dO^T fragment: [d][q-slots]
+                qf[i] = tr_frag(cq + off, 8 * QP);        // Q^T fragment
+            }
+        };
+        if (!DROP) load_tr();                             // (the dropout variant has no registers to spare for this overlap)
+        __builtin_amdgcn_sched_barrier(0);
         // lane: key column kl, rows q = (r%4) + 8*(r/4) + 4*h2
         float pd[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lseq[qq], 0.f));
+            const float lq = reinterpret_cast<const float*>(&l4[r >> 2])[r & 3];
+            const float dq_ = reinterpret_cast<const float*>(&d4[r >> 2])[r & 3];
+            const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lq, 0.f));
             float keep = 1.f;
-            if (p.drop_thresh) {
+            if (DROP) {
+                const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
                 const unsigned long long idx = ((unsigned long long)blockIdx.y * T + (q0 + qq)) * T + key;
                 keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
             }
             pd[r] = pr * keep;                                   // dropped probabilities feed dV
-            ds[r] = pr * (dp[r] * keep - delq[qq]) * scale;     // dS feeds dK
+            ds[r] = pr * (dp[r] * keep - dq_) * scale;          // dS feeds dK
+        }
+        // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+        if (DROP) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_tr();
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 pf, df;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)pd[8 * s2 + e]; df[e] = (bf16_t)ds[8 * s2 + e]; }
-            const int r0 = 16 * s2 + 4 * h2;      // query rows of k-slots e<4; e>=4 are 8 rows further
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int off = (r0 + (a16 >> 2)) * QP + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
-                const bf16x8 gf = tr_frag(ldsG + off, 8 * QP);    // dO^T fragment: [q-slots][d]
-                const bf16x8 qf = tr_frag(ldsQ + off, 8 * QP);    // Q^T fragment
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, gf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qf, dk[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
             }
         }
         if (more) {
+            qg_commit(lds + (cur ^ 1) * QBUF);            // the other stage: last read before the previous barrier
             __syncthreads();
-            qg_commit(q0 + QT, nq, ng);
-            __syncthreads();
+            cur ^= 1;
         }
     }
-    // dk/dv accumulators: rows = keys (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32
-    bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64;
+    // dk/dv accumulators (transposed): column = this lane's key, rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
+    if (kvalid) {
+        bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)key * RS;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = blockIdx.x * (nthr >> 1) + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            if (krow < T) {
-                dbase[(long)krow * RS + p.H * 64 + db * 32 + kl] = (bf16_t)dk[db][r];
-                dbase[(long)krow * RS + 2 * p.H * 64 + db * 32 + kl] = (bf16_t)dv[db][r];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                store_bf16x4(drow + p.H * 64 + d, dk[db][4 * r4], dk[db][4 * r4 + 1], dk[db][4 * r4 + 2], dk[db][4 * r4 + 3]);
+                store_bf16x4(drow + 2 * p.H * 64 + d, dv[db][4 * r4], dv[db][4 * r4 + 1], dv[db][4 * r4 + 2], dv[db][4 * r4 + 3]);
             }
-        }
+    }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * KP16 + KT * 4];
     char* ldsK = lds;
@@ -609,49 +659,60 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     kv_direct(base, RS, HD, 0, T, ldsK, ldsV, KP16, tid, nthr);
     kbias_fill(kbias, p.mask, b, 0, T, tid);
     __syncthreads();
+    asm volatile("" ::"v"(qr[0]), "v"(qr[1]), "v"(qr[2]), "v"(qr[3]), "v"(gr[0]), "v"(gr[1]), "v"(gr[2]), "v"(gr[3]));   // see the forward kernel
     for (int kv0 = 0; kv0 < T; kv0 += KT) {
         const bool more = kv0 + KT < T;
         KVRegs nxt;
         if (more) kv_fetch(nxt, base, RS, HD, kv0 + KT, T, tid, nthr);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            if (kv0 + kb * 32 >= T) continue;
+            if (kb == 1 && kv0 + 32 >= T) break;          // the second 32-key block is all padding
             // S^T[key][q], dP^T[key][q]: rows = keys (A from LDS), columns = queries (B = this lane's Q / dO row)
+            bf16x8 ak[4], av[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                ak[kk] = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
+                av[kk] = ld_bf16x8(ldsV + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 ak = ld_bf16x8(ldsK + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
-                const bf16x8 av = ld_bf16x8(ldsV + (kb * 32 + ql) * KP16 + (2 * kk + h2) * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qr[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gr[kk], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[kk], qr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kk], gr[kk], dp, 0, 0, 0);
             }
+            float4 b4[4];                                 // key bias of this lane's 16 key rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(kbias + kb * 32 + 8 * j + 4 * h2);
+            bf16x8 kf[4];                                 // K^T fragments [d][key-slots], index s2 * 2 + db
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                kf[i] = tr_frag(ldsK + (kb * 32 + 16 * (i >> 1) + 4 * h2 + (a16 >> 2)) * KP16 + ((i & 1) * 32 + 16 * g16 + 4 * (a16 & 3)) * 2,
+                                8 * KP16);
+            __builtin_amdgcn_sched_barrier(0);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kbias[kk_] - lse, 0.f));
+                const float kbv = reinterpret_cast<const float*>(&b4[r >> 2])[r & 3];
+                const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kbv - lse, 0.f));
                 float keep = 1.f;
-                if (p.drop_thresh) {
+                if (DROP) {
+                    const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
                     const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + (kv0 + kk_);
                     keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
                 }
                 ds[r] = pr * (dp[r] * keep - del) * scale;
             }
-            // dQ[q][d] += dS[q][keys] . K[keys][d] : A = dS (this lane's query row, key k-slots), B = K^T via tr reads
+            // dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 df;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) df[e] = (bf16_t)ds[8 * s2 + e];
-                const int k0 = kb * 32 + 16 * s2 + 4 * h2;
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* kp = ldsK + (k0 + (a16 >> 2)) * KP16 + (db * 32 + 16 * g16 + 4 * (a16 & 3)) * 2;
-                    const bf16x8 kf = tr_frag(kp, 8 * KP16);
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, kf, dq[db], 0, 0, 0);
-                }
+                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
             }
         }
         if (more) {
@@ -661,15 +722,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
             __syncthreads();
         }
     }
-    // dq accumulators: rows = queries (r%4)+8*(r/4)+4*h2 of this wave's 32, columns d = db*32 + lane%32
-    bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64;
+    // dq accumulators (transposed): column = this lane's query, rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
+    if (qvalid) {
+        bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)q * RS;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qrow = blockIdx.x * (nthr >> 1) + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            if (qrow < T) dbase[(long)qrow * RS + db * 32 + ql] = (bf16_t)dq[db][r];
-        }
+            for (int r4 = 0; r4 < 4; ++r4)
+                store_bf16x4(drow + db * 32 + 8 * r4 + 4 * h2, dq[db][4 * r4], dq[db][4 * r4 + 1], dq[db][4 * r4 + 2], dq[db][4 * r4 + 3]);
+    }
 }
 
 // Waves (= 32-query tiles) per block.  The kernels hold 2-3 waves per SIMD (register bound), i.e. 8-12 waves per CU:
@@ -754,8 +815,13 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(nw * 64), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(nw * 64), 0, s, p);
+    if (p.drop_thresh) {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(nw * 64), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(nw * 64), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(nw * 64), 0, s, p);
+    }
     SS_LAUNCH_CHECK("attention_bwd");
     return 0;
 }

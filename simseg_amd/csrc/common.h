@@ -54,6 +54,12 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 // counter-based RNG for dropout: one 32-bit hash per element index, reproducible in backward
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
     uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
