@@ -1,0 +1,102 @@
+"""TEST INFRASTRUCTURE ONLY - CPU restatement of the reference's per-image segmentation post-processing
+(tools/seg_evaluation.py:112-170) in numpy / torch, one image at a time, written as explicit loops.
+
+Pinning: `intersect_and_union` is pinned against the reference's own function (tests/golden/miou.npz, oracle/make_golden.py).
+The stage between the normalised map and the morphology is a CPU DenseCRF from `pydensecrf` (requirements.txt) and the
+morphology / resize are `cv2` calls; neither package exists in this image, so that stretch is PARITY UNPINNED: the CRF is
+replaced by its unary decision (prob > 0.5, see dense_crf :34-41: U = -log([1-p, p]), argmax of the unaries alone), and
+cv2.dilate / cv2.erode / cv2.resize(INTER_NEAREST) are restated from their documented semantics (7x7 rectangular kernel,
+anchor at the centre, one iteration, border pixels never win; src = floor(dst * src_size / dst_size)) and cross-checked
+against scipy.ndimage in tests/test_oracle_golden.py.
+"""
+import numpy as np
+import torch
+
+
+def select_candidates(scores, top_cls_num, ncand=5):
+    """:121-123, :128-133, :145-146.  scores [C] float32 tensor -> (idx list with -1 for skipped slots, scores, threshold)."""
+    topk_scores, topk_index = scores.topk(min(top_cls_num, scores.numel()))
+    threshold = topk_scores.mean() + 1.0 * topk_scores.std()
+    idx, sc = [], []
+    broke = False
+    for i, index in enumerate(topk_index[:ncand].tolist()):
+        s = float(scores[index])
+        sc.append(s)
+        if index in [0, 255]:
+            idx.append(-1)
+            continue
+        if broke or s < float(threshold):
+            broke = True
+            idx.append(-1)
+            continue
+        idx.append(index)
+    while len(idx) < ncand:
+        idx.append(-1); sc.append(0.0)
+    return idx, sc, float(threshold)
+
+
+def normalised_map(sim_col, n, patch=16):
+    """:135-149: column of the similarity map -> n x n -> nearest x16 -> min-max normalise.  Returns (prob [16n,16n], binary)."""
+    a = sim_col.reshape(n, n).astype(np.float32)
+    up = np.repeat(np.repeat(a, patch, axis=0), patch, axis=1)
+    mn, mx = up.min(), up.max()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        norm = (up - mn) / (mx - mn)
+    binary = (norm > 0.5).astype(np.uint8) * 255            # dense_crf with the pairwise terms off: argmax of [1-p, p]
+    return norm, binary
+
+
+def morph7(img, erode):
+    """cv2.dilate / cv2.erode(img, np.ones((7,7)), iterations=1), default border: out-of-image pixels never win."""
+    H, W = img.shape
+    out = np.empty_like(img)
+    for y in range(H):
+        y0, y1 = max(0, y - 3), min(H, y + 4)
+        for x in range(W):
+            x0, x1 = max(0, x - 3), min(W, x + 4)
+            win = img[y0:y1, x0:x1]
+            out[y, x] = win.min() if erode else win.max()
+    return out
+
+
+def resize_nearest(img, H, W):
+    """cv2.resize(img, (W, H), interpolation=cv2.INTER_NEAREST): src index = min(floor(dst * src / dst_size), src - 1)."""
+    h, w = img.shape
+    ys = np.minimum(np.floor(np.arange(H) * (h / H)).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(W) * (w / W)).astype(np.int64), w - 1)
+    return img[ys][:, xs]
+
+
+def intersect_and_union(pred, label, num_classes, ignore_index=255):
+    """simseg/utils/metrics.py:52-74 (pinned by tests/golden/miou.npz through oracle/simseg_ref.intersect_and_union)."""
+    pred = torch.as_tensor(pred).long()
+    label = torch.as_tensor(label).long()
+    m = label != ignore_index
+    pred, label = pred[m], label[m]
+    inter = pred[pred == label]
+    a_i = torch.histc(inter.float(), bins=num_classes, min=0, max=num_classes - 1)
+    a_p = torch.histc(pred.float(), bins=num_classes, min=0, max=num_classes - 1)
+    a_l = torch.histc(label.float(), bins=num_classes, min=0, max=num_classes - 1)
+    return a_i, a_p, a_l
+
+
+def segment_image(sim, scores, label, n, top_cls_num, ncand=5, closing=True, fast_morph=None):
+    """One image.  sim [n*n, C] float32 numpy, scores [C] torch float32, label [H,W] uint8 numpy ->
+    dict(pred [H,W] int64, cand_idx, cand_score, threshold, masks [ncand,16n,16n], hist [3,C])."""
+    C = sim.shape[1]
+    H, W = label.shape
+    idx, sc, thr = select_candidates(scores, top_cls_num, ncand)
+    temp_pred = np.zeros((C, H, W))                                              # :126 (float64)
+    masks = np.zeros((ncand, 16 * n, 16 * n), np.uint8)
+    mf = fast_morph or morph7
+    for k, index in enumerate(idx):
+        if index < 0:
+            continue
+        _, binary = normalised_map(sim[:, index], n)
+        final = mf(mf(binary, False), True) if closing else binary               # :155-157
+        masks[k] = final
+        temp_pred[index] = resize_nearest(final, H, W) * sc[k]                   # :159-160
+    pred = temp_pred.argmax(0)                                                   # :163
+    a_i, a_p, a_l = intersect_and_union(pred, label, C)
+    return {"pred": pred, "cand_idx": idx, "cand_score": sc, "threshold": thr, "masks": masks,
+            "hist": torch.stack([a_i, a_p, a_l]).long()}

@@ -267,3 +267,54 @@ def tr16_probe():
     out = torch.empty(256, device="cuda", dtype=torch.int32)
     call("simseg_debug_tr16_probe", ptr(out), stream())
     return out.cpu().view(64, 4)
+
+
+# ---- zero-shot segmentation post-processing (tools/seg_evaluation.py:112-170) ------------------------------------------------
+def seg_select(scores, top_cls_num, ncand=5):
+    """scores [B,C] fp32 -> (cand_idx [B,ncand] int32 (-1 = slot skipped), cand_score [B,ncand] fp32, threshold [B] fp32)."""
+    require_gpu(scores)
+    B, C = scores.shape
+    idx = torch.empty(B, ncand, device=scores.device, dtype=torch.int32)
+    sc = torch.empty(B, ncand, device=scores.device, dtype=torch.float32)
+    thr = torch.empty(B, device=scores.device, dtype=torch.float32)
+    call("simseg_seg_select", ptr(_c(scores.float())), ptr(idx), ptr(sc), ptr(thr), B, C, int(top_cls_num), int(ncand), stream())
+    return idx, sc, thr
+
+
+def seg_masks(sim, cand_idx, n, want_prob=False):
+    """sim [B,n*n,C] fp32, cand_idx [B,ncand] -> mask [B,ncand,16n,16n] uint8 (0/255; skipped slots all zero), prob or None."""
+    require_gpu(sim, cand_idx)
+    B, N, C = sim.shape
+    if N != n * n:
+        raise ValueError(f"seg_masks: sim has {N} patches, expected {n}x{n}")
+    ncand = cand_idx.shape[1]
+    mask = torch.zeros(B, ncand, 16 * n, 16 * n, device=sim.device, dtype=torch.uint8)
+    prob = torch.zeros(B, ncand, N, device=sim.device, dtype=torch.float32) if want_prob else None
+    call("simseg_seg_masks", ptr(_c(sim)), ptr(_c(cand_idx)), ptr(prob) if want_prob else None, ptr(mask), B, n, C, ncand, stream())
+    return mask, prob
+
+
+def morph7(img, erode):
+    """7x7 dilate (erode=False) / erode (True), one iteration, on uint8 [..., H, W]."""
+    require_gpu(img)
+    if img.dtype != torch.uint8:
+        raise TypeError("morph7: uint8 images")
+    x = _c(img)
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    call("simseg_morph7", ptr(x), ptr(out), x.numel() // (H * W), H, W, int(bool(erode)), stream())
+    return out
+
+
+def seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index=255, hist=None, want_pred=True):
+    """masks [B,ncand,Hm,Wm] uint8, labels [B,H,W] uint8 -> (pred [B,H,W] int32 or None, hist [3,C] int64 accumulated:
+    rows = intersect, pred area, label area)."""
+    require_gpu(masks, labels)
+    B, ncand, Hm, Wm = masks.shape
+    _, H, W = labels.shape
+    if hist is None:
+        hist = torch.zeros(3, num_classes, device=masks.device, dtype=torch.int64)
+    pred = torch.empty(B, H, W, device=masks.device, dtype=torch.int32) if want_pred else None
+    call("simseg_seg_predict", ptr(_c(masks)), ptr(_c(cand_idx)), ptr(_c(cand_score)), ptr(_c(labels)), ptr(pred) if want_pred else None,
+         ptr(hist), B, ncand, Hm, Wm, H, W, int(num_classes), int(ignore_index), stream())
+    return pred, hist

@@ -1,0 +1,167 @@
+"""Zero-shot segmentation post-processing: oracle self-checks on CPU, kernels vs oracle on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import segpost_ref as SR
+from oracle import simseg_ref as R
+
+
+def _scene(seed, B=3, n=14, C=21, H=200, W=300, boost=(3, 7, 0, 12)):
+    g = torch.Generator().manual_seed(seed)
+    sim = torch.randn(B, n * n, C, generator=g) * 0.1
+    # smooth blobs so the masks have structure
+    yy, xx = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+    for b in range(B):
+        for k, c in enumerate(boost):
+            cy, cx = (3 + 4 * k + b) % n, (2 + 5 * k + 2 * b) % n
+            sim[b, :, c] += torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 18.0).reshape(-1) * 0.5
+    scores = torch.randn(B, C, generator=g) * 0.05
+    for k, c in enumerate(boost):
+        scores[:, c] += 0.4 - 0.05 * k                   # class 0 among the leaders: must be skipped, not chosen
+    labels = torch.randint(0, C, (B, H, W), generator=g, dtype=torch.int64).to(torch.uint8)
+    labels[torch.rand(B, H, W, generator=g) < 0.05] = 255
+    return sim, scores, labels
+
+
+# ------------------------------------------------------------------------------------------------------------------ CPU
+def test_oracle_morph7_matches_scipy():
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(0)
+    img = (rng.random((45, 61)) < 0.2).astype(np.uint8) * 255
+    grey = rng.integers(0, 256, (33, 40), dtype=np.uint8)
+    for im in (img, grey):
+        assert np.array_equal(SR.morph7(im, False), ndi.grey_dilation(im, size=(7, 7), mode="constant", cval=0))
+        assert np.array_equal(SR.morph7(im, True), ndi.grey_erosion(im, size=(7, 7), mode="constant", cval=255))
+
+
+def test_oracle_closing_is_identity_on_patch_maps():
+    # a x16 nearest-upsampled binary map has no gap narrower than 16 px, so the reference's 7x7 dilate+erode leaves it
+    # unchanged when no CRF ran in between - the property the full-size GPU test relies on
+    rng = np.random.default_rng(1)
+    cells = (rng.random((6, 6)) < 0.4).astype(np.uint8) * 255
+    up = np.repeat(np.repeat(cells, 16, 0), 16, 1)
+    assert np.array_equal(SR.morph7(SR.morph7(up, False), True), up)
+
+
+def test_oracle_resize_and_iou_against_pinned_metric():
+    img = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    out = SR.resize_nearest(img, 6, 8)
+    assert out.shape == (6, 8) and np.array_equal(out[::2, ::2], img)
+    assert np.array_equal(SR.resize_nearest(img, 3, 4), img)
+    g = torch.Generator().manual_seed(2)
+    pred = torch.randint(0, 7, (40, 50), generator=g)
+    lab = torch.randint(0, 7, (40, 50), generator=g)
+    lab[torch.rand(40, 50, generator=g) < 0.1] = 255
+    a_i, a_p, a_l = SR.intersect_and_union(pred, lab, 7)
+    i2, u2 = R.intersect_and_union(pred, lab, 7)              # restatement pinned by tests/golden/miou.npz
+    assert torch.equal(a_i, i2) and torch.equal(a_p + a_l - a_i, u2)
+
+
+def test_oracle_candidate_rules():
+    s = torch.tensor([0.9, 0.1, 0.8, 0.7, 0.05, 0.0, -0.1, 0.02, 0.01, 0.03, 0.04, 0.06])
+    idx, sc, thr = SR.select_candidates(s, 10)
+    assert idx[0] == -1                                    # class 0 leads and is skipped
+    assert idx[1] == 2 and idx[2] == 3                     # above mean + std
+    assert idx[3] == -1 and idx[4] == -1                   # below the threshold: break
+    assert abs(thr - float(s.topk(10)[0].mean() + s.topk(10)[0].std())) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_select_masks_predict_vs_oracle():
+    from simseg_amd import ops, segpost
+    sim, scores, labels = _scene(11)
+    B, N, C = sim.shape
+    n = 14
+    out = segpost.segment(sim.cuda(), scores.cuda(), labels.cuda(), n, top_cls_num=10)
+    hist_ref = torch.zeros(3, C, dtype=torch.int64)
+    for b in range(B):
+        ref = SR.segment_image(sim[b].numpy(), scores[b], labels[b].numpy(), n, 10)
+        assert out["cand_idx"][b].tolist() == ref["cand_idx"]
+        assert abs(float(out["threshold"][b]) - ref["threshold"]) < 1e-6
+        assert np.array_equal(out["masks"][b].cpu().numpy(), ref["masks"])         # bit-exact byte maps
+        assert np.array_equal(out["pred"][b].cpu().numpy(), ref["pred"])           # bit-exact label maps
+        hist_ref += ref["hist"]
+    assert torch.equal(out["hist"].cpu(), hist_ref)
+    assert any(i >= 0 for row in out["cand_idx"].tolist() for i in row)
+    iou, miou = segpost.iou_from_hist(out["hist"])
+    i_ref = hist_ref[0].double() / (hist_ref[1] + hist_ref[2] - hist_ref[0]).double()
+    assert torch.allclose(iou.cpu()[~torch.isnan(i_ref)], i_ref[~torch.isnan(i_ref)], atol=0, rtol=0)
+
+
+@pytest.mark.gpu
+def test_select_edge_cases():
+    from simseg_amd import ops
+    # class 255 among the leaders (a 256-class table), ties, everything below the threshold except the first
+    C = 300
+    s = torch.zeros(2, C)
+    s[0, 255] = 0.9; s[0, 17] = 0.8; s[0, 0] = 0.7; s[0, 40] = 0.6; s[0, 41] = 0.6
+    s[1, 5] = 1.0
+    idx, sc, thr = ops.seg_select(s.cuda(), 30, 5)
+    for b in range(2):
+        ri, rs, rt = SR.select_candidates(s[b], 30)
+        assert idx[b].tolist() == ri, (idx[b].tolist(), ri)
+        assert torch.allclose(sc[b].cpu(), torch.tensor(rs), atol=1e-7)
+        assert abs(float(thr[b]) - rt) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 45, 61), (1, 64, 64), (3, 130, 257)])
+def test_morph7_vs_oracle(shape):
+    from simseg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    binary = (torch.rand(shape, generator=g) < 0.15).to(torch.uint8) * 255
+    grey = torch.randint(0, 256, shape, generator=g, dtype=torch.int64).to(torch.uint8)
+    for img in (binary, grey):
+        for erode in (False, True):
+            got = ops.morph7(img.cuda(), erode).cpu().numpy()
+            for m in range(shape[0]):
+                assert np.array_equal(got[m], SR.morph7(img[m].numpy(), erode))
+
+
+@pytest.mark.gpu
+def test_refine_hook_and_closing_on_irregular_masks():
+    # a caller-supplied refinement (stands in for a CRF) produces masks that are NOT patch aligned: the morphology matters
+    from simseg_amd import segpost
+    sim, scores, labels = _scene(13, B=2, n=8, C=12, H=100, W=90, boost=(3, 7, 5, 9))
+    g = torch.Generator().manual_seed(3)
+    noise = (torch.rand(2, 5, 128, 128, generator=g) < 0.03)
+
+    def refine(prob, cand_idx, cand_score):
+        return (((prob > 0.5) ^ noise.to(prob.device)).to(torch.uint8) * 255)
+
+    out = segpost.segment(sim.cuda(), scores.cuda(), labels.cuda(), 8, top_cls_num=10, refine=refine)
+    for b in range(2):
+        idx, sc, thr = SR.select_candidates(scores[b], 10)
+        temp = np.zeros((12, 100, 90))
+        for k, index in enumerate(idx):
+            if index < 0:
+                continue
+            norm, _ = SR.normalised_map(sim[b, :, index].numpy(), 8)
+            m = ((norm > 0.5) ^ noise[b, k].numpy()).astype(np.uint8) * 255
+            m = SR.morph7(SR.morph7(m, False), True)
+            temp[index] = SR.resize_nearest(m, 100, 90) * sc[k]
+        assert np.array_equal(out["pred"][b].cpu().numpy(), temp.argmax(0))
+
+
+@pytest.mark.gpu
+def test_fullsize_512_window_properties():
+    # BASELINE configs[3] shape: 512x512 windows (n = 32), 171 classes.  Size-independent properties: closing is the
+    # identity on patch-aligned maps; histogram rows add up to the number of non-ignored pixels; pred only holds candidates.
+    from simseg_amd import ops, segpost
+    g = torch.Generator().manual_seed(7)
+    B, n, C = 8, 32, 171
+    sim = torch.randn(B, n * n, C, generator=g).cuda()
+    scores = torch.randn(B, C, generator=g).cuda()
+    labels = torch.randint(0, C, (B, 512, 512), generator=g, dtype=torch.int64).to(torch.uint8)
+    labels[torch.rand(B, 512, 512, generator=g) < 0.05] = 255
+    labels = labels.cuda()
+    a = segpost.segment(sim, scores, labels, n, 10, closing=True)
+    b = segpost.segment(sim, scores, labels, n, 10, closing=False)
+    assert torch.equal(a["masks"], b["masks"]) and torch.equal(a["pred"], b["pred"]) and torch.equal(a["hist"], b["hist"])
+    valid = int((labels != 255).sum())
+    assert int(a["hist"][1].sum()) == valid and int(a["hist"][2].sum()) == valid
+    assert int(a["hist"][0].sum()) == int(((a["pred"] == labels.int()) & (labels != 255)).sum())
+    allowed = set([0] + [i for row in a["cand_idx"].tolist() for i in row if i >= 0])
+    assert set(a["pred"].unique().tolist()) <= allowed
