@@ -98,8 +98,9 @@ def cpu_baseline(img, L, budget_s=20.0):
 
 def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
     """Zero-shot segmentation GPU stage (BASELINE configs[3] shape): ViT-B on 512x512 windows -> projection -> LoDA pooled
-    embedding + dense patch x class-text similarity map for all `classes` (tools/seg_evaluation.py:99-143 without the CPU
-    CRF stage).  Independent windows: sharded over ranks with no collective.  Returns windows/s over all ranks."""
+    embedding + dense patch x class-text similarity map for all `classes` + candidate selection, masks, 7x7 morphology,
+    resize/argmax and IoU histograms on the device (tools/seg_evaluation.py:99-170 without the CPU CRF stage).  Independent
+    windows: sharded over ranks, no collective on the data path (one all-reduce of the [3,C] histograms at the end)."""
     from simseg_amd.heads import patch_text_similarity
     from simseg_amd import ops
     from simseg.models import PIPELINE
@@ -110,7 +111,13 @@ def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171,
     g = torch.Generator().manual_seed(3)
     text = torch.nn.functional.normalize(torch.randn(classes, 512, generator=g), dim=-1).to(dev)
     images = torch.randn(windows, 3, img, img, generator=g).to(dev)
+    labels = torch.randint(0, classes, (windows, img, img), generator=g, dtype=torch.int64).to(torch.uint8)
+    labels[torch.rand(windows, img, img, generator=g) < 0.05] = 255
+    labels = labels.to(dev)
+    hist = torch.zeros(3, classes, device=dev, dtype=torch.int64)
     cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    from simseg_amd import segpost
+    post_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def step():
         with torch.no_grad():
@@ -119,7 +126,11 @@ def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171,
             tok = model.image_projection(feats)                         # [B, 1024, 512]
             sim = patch_text_similarity(tok, text, compute_dtype=cdt)   # [B, 1024, classes]
             scores = ops.gemm(pooled, text)                             # [B, classes]
-        return sim, scores
+            # post-processing of tools/seg_evaluation.py:112-170 on the device (the CPU DenseCRF is outside the path)
+            post_ev[0].record()
+            out = segpost.segment(sim, scores, labels, img // 16, 10, hist=hist, want_pred=False)
+            post_ev[1].record()
+        return sim, scores, out
 
     step()
     torch.cuda.synchronize()
@@ -130,12 +141,18 @@ def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171,
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hist)               # the only exchange of the seg path - intersect / area histograms, once
     del model
     n_patches = (img // 16) ** 2
     t = n_patches + 1
     fl = 12 * (24 * t * dim * dim + 4 * t * t * dim) + 2 * n_patches * 768 * dim + 2 * 2 * n_patches * dim * 512 + 2 * n_patches * 512 * classes
     wps = world * windows * steps / float(el)
-    return {"windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
+    post_ms = post_ev[0].elapsed_time(post_ev[1])
+    # algorithmic bytes of the post stage per window: 5 candidate maps of (img x img) bytes are written once, dilated and
+    # eroded (read + write each), read again with the label map for the argmax / IoU pass
+    post_bytes = windows * img * img * (5 + 4 * 5 + 5 + 1)
+    return {"post_ms_per_step": round(post_ms, 3), "post_GBps": round(post_bytes / post_ms / 1e6, 1),
+            "post_frac_of_hbm_peak": round(post_bytes / post_ms / 1e6 / 8000.0, 4), "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
             "classes": classes, "windows_per_step_per_gpu": windows, "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
             "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
 

@@ -184,9 +184,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-// Multi-tensor form: one launch for every parameter tensor.  table[t] = {p, g, m, v} device pointers, sizes[t] elements;
-// chunk c of the launch covers elements [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tid[c].
-struct AdamTensors { float* p; const float* g; float* m; float* v; };
+// Multi-tensor form: one launch for every parameter tensor.  table[t] = {p, g, m, v, p16} device pointers, sizes[t] elements;
+// chunk c of the launch covers elements [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tid[c].  p16 (may be null) is the
+// bf16 compute copy the next forward's GEMMs read: refreshed here, so no per-step cast kernels.
+struct AdamTensors { float* p; const float* g; float* m; float* v; bf16_t* p16; };
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __restrict__ table, const long* __restrict__ sizes,
                                                           const int* __restrict__ chunk_tid, const long* __restrict__ chunk_off,
                                                           int chunk, float lr, float b1, float b2, float eps, const float* __restrict__ wd,
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __r
         const float vi = b2 * T.v[i] + (1.0f - b2) * gi * gi;
         pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
         T.p[i] = pi; T.m[i] = mi; T.v[i] = vi;
+        if (T.p16) T.p16[i] = (bf16_t)pi;
     }
 }
 

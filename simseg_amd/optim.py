@@ -1,12 +1,15 @@
 """AdamW on the fused HIP kernels.  Same update rule and hyper-parameters as the reference's torch.optim.AdamW
 (configs/clip/simseg.vit-b.yaml:31-36); state (m, v) is fp32.  All parameter tensors of a param group are updated by ONE
-kernel launch (simseg_adamw_multi_step): a device table of {p, g, m, v} pointers is refreshed from a pinned host buffer each
-step (gradient tensors are re-allocated by autograd), without a host-device synchronisation."""
+kernel launch (simseg_adamw_multi_step): a device table of {p, g, m, v, p16} pointers is refreshed from a pinned host buffer each
+step (gradient tensors are re-allocated by autograd), without a host-device synchronisation.  p16 is the bf16 compute copy of
+the parameter, written by the same kernel and handed to the towers (towers.register_w16), so a training step launches no
+weight-cast kernels."""
 import numpy as np
 import torch
 
 from . import ops
 from .lib import call, ptr, stream
+from .towers import register_w16
 
 CHUNK = 1 << 16
 
@@ -27,6 +30,7 @@ class AdamW(torch.optim.Optimizer):
         total = sum(p.numel() for p in params)
         m = torch.zeros(total, device=dev, dtype=torch.float32)
         v = torch.zeros(total, device=dev, dtype=torch.float32)
+        p16 = torch.empty(total, device=dev, dtype=torch.bfloat16)
         old = self._plans.get(gi)
         offs, o = [], 0
         for p in params:
@@ -35,16 +39,17 @@ class AdamW(torch.optim.Optimizer):
             if "m" in st:                     # keep moments across a re-plan
                 m[o:o + p.numel()].copy_(st["m"].reshape(-1)); v[o:o + p.numel()].copy_(st["v"].reshape(-1))
             st["m"], st["v"] = m[o:o + p.numel()].view_as(p), v[o:o + p.numel()].view_as(p)
+            st["p16"] = p16[o:o + p.numel()].view_as(p)
             o += p.numel()
         tid, coff = [], []
         for t, p in enumerate(params):
             for c in range(0, p.numel(), CHUNK):
                 tid.append(t); coff.append(c)
-        plan = dict(key=key, m=m, v=v,
+        plan = dict(key=key, m=m, v=v, p16=p16,
                     sizes=torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev),
                     tid=torch.tensor(tid, dtype=torch.int32, device=dev), coff=torch.tensor(coff, dtype=torch.int64, device=dev),
-                    host=torch.empty(len(params), 4, dtype=torch.int64).pin_memory(),
-                    table=torch.empty(len(params), 4, dtype=torch.int64, device=dev), n_chunks=len(tid))
+                    host=torch.empty(len(params), 5, dtype=torch.int64).pin_memory(),
+                    table=torch.empty(len(params), 5, dtype=torch.int64, device=dev), n_chunks=len(tid))
         self._plans[gi] = plan
         return plan
 
@@ -63,6 +68,7 @@ class AdamW(torch.optim.Optimizer):
             for t, (p, g) in enumerate(zip(params, grads)):
                 st = self.state[p]
                 host[t, 0], host[t, 1], host[t, 2], host[t, 3] = p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
+                host[t, 4] = st["p16"].data_ptr()
             plan["table"].copy_(plan["host"], non_blocking=True)
             wd = plan.get("wd")
             if wd is None or plan.get("wd_val") != group["weight_decay"]:
@@ -72,3 +78,5 @@ class AdamW(torch.optim.Optimizer):
                  CHUNK, float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), ptr(wd),
                  self._step, float(grad_scale), stream())
             plan["keepalive"] = grads        # the kernel reads them asynchronously
+            for p in params:                 # same stream as the next forward: the copies are current when it runs
+                register_w16(p, self.state[p]["p16"])

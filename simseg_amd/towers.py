@@ -7,6 +7,8 @@ that block's backward finishes -- torch DDP's bucketed RCCL all-reduce overlaps 
 
 Reference arithmetic: timm 0.6.13 VisionTransformer as driven by simseg/models/backbones/mml/vit_builder.py:13-21,
 HF BertModel as driven by huggingface_builder.py:16-17 (both third-party; see oracle/simseg_ref.py)."""
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -15,10 +17,36 @@ from . import ops
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+_W16 = {}      # id(parameter) -> (weakref(parameter), parameter._version, parameter.data_ptr(), bf16 copy)
+
+
+def register_w16(param, w16):
+    """The optimizer's kernel has just written `w16` = bf16(param) (raw-pointer update: param._version does not move)."""
+    _W16[id(param)] = (weakref.ref(param), param._version, param.data_ptr(), w16)
+
+
+def invalidate_weight_cache():
+    """Drop every cached bf16 weight copy.  Needed only after writes torch cannot see (in-place ops on `param.data`, which
+    carry their own version counter); load_state_dict / copy_ / optimizers / .to() are detected without it."""
+    _W16.clear()
+
+
 def _wt(w, adt):
-    """Weight in the activation dtype (bf16 compute copy of the fp32 master, like autocast's per-step cast)."""
-    w = w.detach()
-    return w if adt == F32 else ops.cast(w.contiguous(), BF16)
+    """Weight in the activation dtype (bf16 compute copy of the fp32 master, like autocast's per-step cast).  The copy is
+    cached per parameter object and reused while the parameter is untouched: torch-side writes bump `_version`, storage
+    swaps change `data_ptr`, and simseg_amd.optim.AdamW refreshes the copy in its own kernel (register_w16)."""
+    if adt == F32:
+        return w.detach()
+    ent = _W16.get(id(w))
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].shape == w.shape:
+        return ent[3]
+    w16 = ops.cast(w.detach().contiguous(), BF16)
+    if isinstance(w, torch.nn.Parameter):
+        if len(_W16) > 4096:
+            for k in [k for k, e in _W16.items() if e[0]() is None]:
+                del _W16[k]
+        _W16[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), w16)
+    return w16
 
 
 def _splitk(m, n, k_rows):
@@ -272,12 +300,7 @@ class BertLayerFn(Function):
         x = x.contiguous()
         save = any(ctx.needs_input_grad)
         xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
-        wqkv = torch.empty(3 * D, D, device=x.device, dtype=adt)
-        for i, w in enumerate((qw, kw, vw)):
-            if adt == F32:
-                wqkv[i * D:(i + 1) * D].copy_(w.detach())
-            else:
-                ops.cast(w.detach().contiguous(), BF16, out=wqkv[i * D:(i + 1) * D])
+        wqkv = torch.cat([_wt(qw, adt), _wt(kw, adt), _wt(vw, adt)])       # HF keeps three matrices; one fused [3D, D] GEMM here
         bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
         ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
         qkv = ops.gemm(xa, wqkv, bias=bqkv)

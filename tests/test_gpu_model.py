@@ -237,3 +237,37 @@ def test_trainer_iteration_and_checkpoint_roundtrip(golden, tmp_path):
     tr2.load_checkpoint(torch.load(path, weights_only=False))
     assert tr2.step == 12
     assert abs(float(tr2.train_step(batch)["loss"]) - nxt) < 1e-6
+
+
+def test_bf16_weight_copy_cache_coherence(golden, monkeypatch):
+    """The towers reuse a cached bf16 copy of each weight; every way the reference's code paths change a weight must be seen:
+    the fused AdamW kernel (refreshes the copy itself), load_state_dict / copy_ (version bump)."""
+    from simseg_amd import towers
+    from simseg_amd.optim import AdamW
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    g = golden("clip_train_ws1")
+    m = _build(golden)
+    m.eval()
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    w = m.image_encoder.model.model.blocks[0].mlp.fc1.weight
+    e0 = m(batch, embeddings="all")[0].clone()
+    assert torch.equal(towers._wt(w, torch.bfloat16), w.detach().bfloat16())
+    c0 = towers._wt(w, torch.bfloat16)
+    assert towers._wt(w, torch.bfloat16) is c0                     # second use: no cast
+    with torch.no_grad():
+        w.mul_(0.5)                                                # torch-visible write
+    assert torch.equal(towers._wt(w, torch.bfloat16), w.detach().bfloat16())
+    e1 = m(batch, embeddings="all")[0]
+    assert (e1 - e0).abs().max() > 1e-4
+    opt = AdamW(m.parameters(), lr=1e-2)
+    loss = m(batch)[0]["nce_loss"]
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    for p in (w, m.text_encoder.model.model.encoder.layer[0].attention.self.query.weight, m.image_projection.linear.weight):
+        ent = towers._W16[id(p)]
+        assert ent[3].data_ptr() == opt.state[p]["p16"].data_ptr()      # the optimizer's copy is the one the towers use
+        assert torch.equal(towers._wt(p, torch.bfloat16), p.detach().bfloat16())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict({k: v * 0 + 0.01 for k, v in sd.items()}, strict=False)
+    assert torch.equal(towers._wt(w, torch.bfloat16), w.detach().bfloat16())
