@@ -55,16 +55,28 @@ def _splitk(m, n, k_rows):
     return max(1, min(nk, (1024 + tiles - 1) // tiles, 64))
 
 
-def _wgrad(dy16, x16):
-    """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K."""
+def _zeros(device, *shapes):
+    """fp32 zero tensors for one block's accumulated gradients, carved from ONE zero-filled buffer (one fill launch per block
+    instead of one per tensor; each view starts on a 256-byte boundary)."""
+    sizes = [int(torch.Size(sh).numel()) if not isinstance(sh, int) else sh for sh in shapes]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 63) // 64 * 64
+    buf = torch.zeros(o, device=device, dtype=F32)
+    return [buf[a:a + n].view(sh) for a, n, sh in zip(offs, sizes, shapes)]
+
+
+def _wgrad(dy16, x16, out=None):
+    """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K atomics into the zero-filled `out`."""
     out_f, in_f = dy16.shape[1], x16.shape[1]
-    dw = torch.zeros(out_f, in_f, device=dy16.device, dtype=F32)
+    dw = torch.zeros(out_f, in_f, device=dy16.device, dtype=F32) if out is None else out
     ops.gemm(dy16, x16, trans_a=True, trans_b=True, out=dw, accumulate=True, splitk=_splitk(out_f, in_f, dy16.shape[0]))
     return dw
 
 
-def _bgrad(dy16):
-    db = torch.zeros(dy16.shape[1], device=dy16.device, dtype=F32)
+def _bgrad(dy16, out=None):
+    db = torch.zeros(dy16.shape[1], device=dy16.device, dtype=F32) if out is None else out
     ops.colsum_accum(dy16, db)
     return db
 
@@ -214,22 +226,21 @@ class ViTBlockFn(Function):
         else:
             dy16 = ops.cast(dy, BF16)
             df2b = _bgrad(dy16) if need[14] else None
+        (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros(
+            dy.device, (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
-        df1b = torch.zeros(4 * D, device=dy.device, dtype=F32)
         dpre = ops.gemm(dy16, f2w_, trans_b=True, act=2, aux=pre, colsum=df1b)
-        df2w = _wgrad(dy16, act) if need[13] else None
+        df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
         dln2 = ops.gemm(dpre, f1w_, trans_b=True)
-        df1w = _wgrad(dpre, ln2) if need[11] else None
-        dn2w, dn2b, dpb = torch.zeros_like(n2w), torch.zeros_like(n2w), torch.zeros_like(n2w)
+        df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
         dx1_32, dx1_16 = ops.layernorm_bwd(x1, mean2, rstd2, n2w, dn2w, dn2b, dy16=dln2, dres=dy, dxsum=dpb)
         # attention
         datt = ops.gemm(dx1_16, pw_, trans_b=True)
-        dpw = _wgrad(dx1_16, att.view(-1, D)) if need[7] else None
+        dpw = _wgrad(dx1_16, att.view(-1, D), dpw_z) if need[7] else None
         dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5).view(-1, 3 * D)
         dln1 = ops.gemm(dqkv, qw_, trans_b=True)
-        dqw = _wgrad(dqkv, ln1.view(-1, D)) if need[5] else None
-        dqb = _bgrad(dqkv) if need[6] else None
-        dn1w, dn1b, dsum = torch.zeros_like(n1w), torch.zeros_like(n1w), torch.zeros_like(n1w)
+        dqw = _wgrad(dqkv, ln1.view(-1, D), dqw_z) if need[5] else None
+        dqb = _bgrad(dqkv, dqb_z) if need[6] else None
         dx, dx16 = ops.layernorm_bwd(x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dy16=dln1, dres=dx1_32, dxsum=dsum)
         dx = dx.view(B, T, D)
         _put_shadow(dx, dx16, dsum)
@@ -326,22 +337,22 @@ class BertLayerFn(Function):
         p, seed = ctx.drop
         need = ctx.needs_input_grad
         dy = dy.contiguous().view(-1, D)
-        dlow, dlob, do2b = torch.zeros_like(low), torch.zeros_like(low), torch.zeros_like(low)
+        I = pre.shape[1]
+        (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros(
+            dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
         ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy, dxsum=do2b, drop_seed=seed + 2, drop_p=p)
-        dib = torch.zeros(pre.shape[1], device=dy.device, dtype=F32)
         dpre = ops.gemm(d2, o2w_, trans_b=True, act=2, aux=pre, colsum=dib)
-        do2w = _wgrad(d2, act) if need[18] else None
+        do2w = _wgrad(d2, act, do2w_z) if need[18] else None
         da = ops.gemm(dpre, iw_, trans_b=True)
-        diw = _wgrad(dpre, aa) if need[16] else None
-        dlaw, dlab, dob = torch.zeros_like(law), torch.zeros_like(law), torch.zeros_like(law)
+        diw = _wgrad(dpre, aa, diw_z) if need[16] else None
         ds1_32, d1 = ops.layernorm_bwd(s1, mean_a, rstd_a, law, dlaw, dlab, dy16=da, dy32=ds2_32, dxsum=dob, drop_seed=seed + 1, drop_p=p)
         datt = ops.gemm(d1, ow_, trans_b=True)
-        dow = _wgrad(d1, att.view(-1, D)) if need[12] else None
+        dow = _wgrad(d1, att.view(-1, D), dow_z) if need[12] else None
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), att, datt.view(B, L, D), lse, ctx.heads, mask, scale=64 ** -0.5,
                                  drop_seed=seed, drop_p=p).view(-1, 3 * D)
         dx = ops.gemm(dqkv, wqkv, trans_b=True, residual=ds1_32, out_dtype=F32)
-        dwqkv = _wgrad(dqkv, xa) if (need[6] or need[8] or need[10]) else None
-        dbqkv = _bgrad(dqkv) if (need[7] or need[9] or need[11]) else None
+        dwqkv = _wgrad(dqkv, xa, dwqkv_z) if (need[6] or need[8] or need[10]) else None
+        dbqkv = _bgrad(dqkv, dbqkv_z) if (need[7] or need[9] or need[11]) else None
         dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]
         dbs = [dbqkv[i * D:(i + 1) * D] if dbqkv is not None else None for i in range(3)]
         return (dx.view(B, L, D), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dow, dob, dlaw, dlab,
