@@ -165,3 +165,20 @@ def test_fullsize_512_window_properties():
     assert int(a["hist"][0].sum()) == int(((a["pred"] == labels.int()) & (labels != 255)).sum())
     allowed = set([0] + [i for row in a["cand_idx"].tolist() for i in row if i >= 0])
     assert set(a["pred"].unique().tolist()) <= allowed
+
+
+@pytest.mark.gpu
+def test_device_eval_tool_synthetic():
+    """tools/seg_eval_device.py end to end on synthetic images (tiny towers): runs the whole per-image body on the GPU and
+    prints the reference's report lines."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29533", PYTHONPATH=repo)
+    cmd = [sys.executable, os.path.join(repo, "tools", "seg_eval_device.py"), "--cfg", os.path.join(repo, "configs/clip/simseg.vit-s.yaml"),
+           "--synthetic", "6", "--batch", "4", "transforms.input_size=96", "model.image_encoder.tag=vit_test_patch16",
+           "model.image_encoder.embedding_dim=128", "model.text_encoder.tag=bert-test", "model.text_encoder.embedding_dim=128"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "6 samples evaluated" in out.stdout and "final mean iou" in (out.stdout + out.stderr)
