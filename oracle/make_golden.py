@@ -175,6 +175,49 @@ def gold_bert():
     _save("bert_tiny", **out, **sd)
 
 
+def gold_vit():
+    """Image tower arithmetic.  timm (the reference's ViT provider, requirements.txt:9) is not installed here; the installed HF
+    transformers ViTModel is the same architecture (its checkpoints are converted from timm's and verified against timm's
+    outputs upstream), so it pins the block arithmetic independently of our restatement: pre-LN blocks, fused-softmax
+    attention with 1/sqrt(d) scaling, erf GELU, final LayerNorm, eps 1e-6, cls + learned position embeddings.  The
+    state dict is saved under timm's parameter names (q/k/v concatenated into attn.qkv, as timm stores them)."""
+    from transformers import ViTConfig, ViTModel
+    from oracle.simseg_ref import VIT_ARCH
+    a = VIT_ARCH["vit_test_patch16"]
+    torch.manual_seed(5)
+    conf = ViTConfig(hidden_size=a["dim"], num_hidden_layers=a["depth"], num_attention_heads=a["heads"], intermediate_size=4 * a["dim"],
+                     image_size=96, patch_size=16, layer_norm_eps=1e-6, hidden_act="gelu", qkv_bias=True, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, attn_implementation="eager")
+    m = ViTModel(conf, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():                # exercise every term: biases, LN affine, cls / pos embeddings
+            p.copy_(torch.randn_like(p) * (0.05 if p.ndim > 1 else 0.1) + (1.0 if ("layernorm" in n and n.endswith("weight")) else 0.0))
+    hf = m.state_dict()
+    sd = {"cls_token": hf["embeddings.cls_token"], "pos_embed": hf["embeddings.position_embeddings"],
+          "patch_embed.proj.weight": hf["embeddings.patch_embeddings.projection.weight"],
+          "patch_embed.proj.bias": hf["embeddings.patch_embeddings.projection.bias"],
+          "norm.weight": hf["layernorm.weight"], "norm.bias": hf["layernorm.bias"]}
+    for i in range(a["depth"]):
+        h = f"layers.{i}." if f"layers.{i}.attention.q_proj.weight" in hf else None
+        if h is None:
+            raise RuntimeError("unexpected transformers ViT parameter naming: " + ", ".join(list(hf)[:12]))
+        t = f"blocks.{i}."
+        for wb in ("weight", "bias"):
+            sd[t + "attn.qkv." + wb] = torch.cat([hf[h + f"attention.{x}_proj.{wb}"] for x in ("q", "k", "v")])
+            sd[t + "attn.proj." + wb] = hf[h + f"attention.o_proj.{wb}"]
+            sd[t + "norm1." + wb] = hf[h + f"layernorm_before.{wb}"]
+            sd[t + "norm2." + wb] = hf[h + f"layernorm_after.{wb}"]
+            sd[t + "mlp.fc1." + wb] = hf[h + f"mlp.fc1.{wb}"]
+            sd[t + "mlp.fc2." + wb] = hf[h + f"mlp.fc2.{wb}"]
+    out = {}
+    for tag, B in {"a": 3, "b": 1}.items():
+        x = torch.randn(B, 3, 96, 96, generator=torch.Generator().manual_seed(30 + B))
+        with torch.no_grad():
+            y = m(pixel_values=x).last_hidden_state
+        out[f"image_{tag}"], out[f"out_{tag}"] = _np(x), _np(y)
+    _save("vit_hf_tiny", **out, **{"sd." + k: _np(v) for k, v in sd.items()})
+
+
 def gold_config():
     """update_cfg results (plain nested dicts, JSON) for both shipped YAMLs with the README's override styles."""
     import json
@@ -347,7 +390,7 @@ def gold_dist(world):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["config", "heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "clip_glue", "dist1", "dist2"]
+    which = sys.argv[1:] or ["config", "heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "vit", "clip_glue", "dist1", "dist2"]
     torch.set_num_threads(4)
     _import_reference()
     for w in which:

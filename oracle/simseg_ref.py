@@ -13,9 +13,13 @@ Pinning status (see DESIGN.md "Oracle"):
     /root/reference/requirements.txt:13, absent from /root/reference).  PINNED against the
     installed transformers' BertModel (eager attention) by oracle/make_golden.py.
   * ViT image tower: the arithmetic lives in timm==0.6.13 (requirements.txt:9), which is
-    not installed and not vendored -> PARITY UNPINNED for the ViT blocks.  The restatement
+    not installed and not vendored, and no test of the reference pins it.  The restatement
     below follows timm 0.6.13 VisionTransformer as called by
-    simseg/models/backbones/mml/vit_builder.py:13-21.
+    simseg/models/backbones/mml/vit_builder.py:13-21, and is PINNED AGAINST AN INDEPENDENT
+    IMPLEMENTATION of the same architecture: the installed transformers' ViTModel (whose
+    checkpoints are conversions of timm's, verified upstream against timm outputs), with
+    its weights re-keyed to timm's names (oracle/make_golden.py gold_vit ->
+    tests/golden/vit_hf_tiny.npz; bit-equal outputs).  Against timm itself: unpinned.
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 """

@@ -92,6 +92,27 @@ def _cos(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
 
 
+def test_vit_tower_vs_hf_golden(golden, monkeypatch):
+    """The HIP ViT tower in fp32 mode against outputs of transformers' ViTModel (fixture vit_hf_tiny): <= 1e-3 (north star)."""
+    from simseg_amd import nn as snn
+    from simseg_amd.towers import vit_forward
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    g = golden("vit_hf_tiny")
+    vit = snn.ViT("vit_test_patch16", img_size=96)
+    sd = {k[3:]: tt(g[k]) for k in g.files if k.startswith("sd.")}
+    missing, unexpected = vit.load_state_dict(sd, strict=True)
+    vit = vit.cuda().eval()
+    for tag in ("a", "b"):
+        with torch.no_grad():
+            y = vit_forward(vit, tt(g[f"image_{tag}"]).cuda(), torch.float32)
+        err = _maxerr(y, tt(g[f"out_{tag}"]))
+        assert err < 1e-3, err
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    with torch.no_grad():
+        y16 = vit_forward(vit, tt(g["image_a"]).cuda(), torch.bfloat16)
+    assert _maxerr(y16, tt(g["out_a"])) < 0.15          # bf16 operands, fp32 residual stream; |y| up to 4.6
+
+
 def test_train_step_ws1_vs_reference_golden(golden, monkeypatch):
     """forward(batch) -> loss -> backward, world size 1, against the reference's own loss/acc/gradients."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")

@@ -85,6 +85,17 @@ def test_bert_vs_hf(golden):
         torch.testing.assert_close(y, tt(g[f"out_{tag}"]), rtol=1e-4, atol=2e-5)
 
 
+def test_vit_vs_hf(golden):
+    """RefViT against the installed transformers ViTModel (the HF port of the timm architecture the reference uses), fixture
+    written by oracle/make_golden.py gold_vit under timm's parameter names."""
+    g = golden("vit_hf_tiny")
+    m = _load_sd(R.RefViT("vit_test_patch16", 96), g).eval()
+    for tag in ("a", "b"):
+        with torch.no_grad():
+            y = m(tt(g[f"image_{tag}"]))
+        torch.testing.assert_close(y, tt(g[f"out_{tag}"]), rtol=1e-5, atol=1e-5)
+
+
 def _ref_clip(g):
     m = R.RefCLIP("vit_test_patch16", "bert-test", img_size=96)
     return _load_sd(m, g).eval()
