@@ -193,7 +193,7 @@ def main():
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("SIMSEG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", 0)))     # override: bring-up of N ranks on one GPU
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     from simseg.utils import ENV
     ENV.local_rank = local

@@ -29,7 +29,10 @@ def init_device(cfg):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl" if has_gpu else "gloo", init_method="env://")
+        # RCCL ("nccl") on GPUs as in the reference; SIMSEG_DIST_BACKEND exists for bring-up (e.g. gloo with several ranks
+        # sharing one GPU, which RCCL refuses)
+        backend = os.environ.get("SIMSEG_DIST_BACKEND") or ("nccl" if has_gpu else "gloo")
+        dist.init_process_group(backend=backend, init_method="env://")
     ENV.rank, ENV.size = dist.get_rank(), dist.get_world_size()
     ENV.device = torch.device("cuda", ENV.local_rank) if has_gpu else torch.device("cpu")
     for name in ("batch_size", "batch_size_val"):
