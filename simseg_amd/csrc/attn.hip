@@ -35,16 +35,33 @@ template <bool FAST> __device__ __forceinline__ float ex2(float x) {
     else return exp2f(x);
 }
 
-template <bool FAST>
+// Block -> (head, row-block) map of every attention kernel.  The launch is 1-D; hardware hands consecutive block ids to
+// consecutive XCDs, so id L runs on XCD L % 8.  All row-blocks of one (batch, head) are given ids of the same residue: the
+// head's K/V (or Q/dO) is then pulled into ONE XCD's L2 and shared by its 2-6 blocks instead of being fetched by each
+// block's own XCD (measured: 3-4 TB/s of L2-miss traffic and waves stalled on tile arrival before this map).
+__device__ __forceinline__ bool attn_block_map(const AttnParams& p, int& qb, int& bh) {
+    const int nw = blockDim.x >> 6;
+    const int gx = ((p.T + 31) / 32 + nw - 1) / nw;
+    const int L = blockIdx.x, slot = L >> 3;
+    bh = (slot / gx) * 8 + (L & 7);
+    qb = slot % gx;
+    return bh < p.B * p.H;
+}
+
+// BIAS: additive per-key bias read from LDS (a key-padding mask was given).  Otherwise only the tile's padding (keys >= klim)
+// is excluded, by comparison: no LDS reads, no registers for the bias.
+template <bool FAST, bool BIAS = true>
 __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias, int h2, float scale_log2e, float& m,
-                                             float& lsum, float& alpha) {
+                                             float& lsum, float& alpha, int klim = 64) {
     float mx = NEG;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const float x = s[kb][r] * scale_log2e + kbias[key];
+            float x;
+            if (BIAS) x = s[kb][r] * scale_log2e + kbias[key];
+            else x = key < klim ? s[kb][r] * scale_log2e : NEG;
             s[kb][r] = x;
             mx = fmaxf(mx, x);
         }
@@ -75,12 +92,14 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(AttnParams p) {
     char* ldsV = lds + KT * KP32;
     float* kbias = reinterpret_cast<float*>(lds + KT * KP32 + KT * VP32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    int qb_, bh_;
+    if (!attn_block_map(p, qb_, bh_)) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = p.T;
     const long RS = 3L * p.H * 64;
     const float* base = static_cast<const float*>(p.qkv) + (long)b * T * RS + h * 64;
     const int nthr = blockDim.x;
-    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
+    const int q = qb_ * (nthr >> 1) + wave * 32 + ql;
 
     float qr[8][4];
 #pragma unroll
@@ -241,22 +260,73 @@ __device__ __forceinline__ void kbias_fill(float* kbias, const long* mask, int b
     }
 }
 
-// DROP: attention_probs dropout compiled in (BERT training only).  DBG: cycle-counter timeline written through p.delta
-// (tools/dbg_attn_timeline.py); the production instantiations carry neither.
-template <bool DROP, bool DBG>
-__global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[KT * KP16 + KT * VP16 + KT * 4];
-    char* ldsK = lds;
-    char* ldsV = lds + KT * KP16;
-    float* kbias = reinterpret_cast<float*>(lds + KT * KP16 + KT * VP16);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+// DROP: attention_probs dropout compiled in (BERT training only).  MASK: a key-padding mask is given (BERT).  DBG: cycle-counter
+// timeline written through p.delta (tools/dbg_attn_timeline.py); the production instantiations do not carry it.
+//
+// K/V tiles of 64 keys go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of three
+// stages, two tiles ahead of the one being consumed - the timeline showed ~5.5 k cycles of global latency under load against
+// ~2.7 k cycles of work per tile, so one tile of lookahead was not enough.  One barrier per tile.  The LDS image of a
+// direct load is lane-linear (1 KiB = 8 key rows of 128 B per wave-instruction), so the rows are unpadded and the bank
+// swizzle is applied to the SOURCE chunk: K slot c of row r holds chunk c ^ ((r>>1)&7) (conflict-free ds_read_b128),
+// V slot c holds chunk c ^ (((r>>1)&1)<<2) (conflict-free ds_read_b64_tr_b16).  Keys past T re-read row T-1 (finite
+// values; their probabilities are exactly 0).
+constexpr int GSTAGE = 2 * KT * 128;     // K then V
+constexpr int GNS = 3;
+constexpr int MAXT_BIAS = 1088;          // key-bias table of a masked sequence (BERT: T <= 512)
+
+__device__ __forceinline__ int k_swz(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int v_swz(int r) { return ((r >> 1) & 1) << 2; }
+
+// this wave's share of one tile: pieces 0..7 = K rows, 8..15 = V rows; every wave issues exactly `per` instructions so
+// the vmcnt bookkeeping is uniform (surplus ones repeat piece 15: same bytes to the same place)
+__device__ __forceinline__ void kv_glds(const bf16_t* base, long RS, int HD, int kv0, int T, char* stage, int wave, int nw, int per,
+                                        int lane) {
+    for (int i = 0; i < per; ++i) {
+        int piece = wave + i * nw;
+        piece = piece < 16 ? piece : 15;
+        const int isv = piece >> 3;
+        const int r = (piece & 7) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (isv ? v_swz(r) : k_swz(r));
+        int key = kv0 + r;
+        key = key < T ? key : T - 1;
+        const bf16_t* src = base + (long)key * RS + (isv + 1) * HD + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + piece * 1024), 16, 0, 0);
+    }
+}
+
+// wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <bool DROP, bool MASK, bool DBG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[GNS * GSTAGE + (MASK ? MAXT_BIAS * 4 : 16)];
+    float* kb_all = reinterpret_cast<float*>(lds + GNS * GSTAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    int qb_, bh_;
+    if (!attn_block_map(p, qb_, bh_)) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = p.T;
     const long RS = 3L * p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
-    const int nthr = blockDim.x;
-    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int per = (16 + nw - 1) / nw;
+    const int q = qb_ * (nthr >> 1) + (tid >> 6) * 32 + ql;
+    const int HD = p.H * 64;
+    const int nt = (T + KT - 1) / KT;
 
+    unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long dt0 = __builtin_readcyclecounter();
+    const unsigned long long dbg_start = dt0;
     bf16x8 qr[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -265,6 +335,12 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
         if (q < T) u.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
         qr[kk] = u.hh;
     }
+    kv_glds(base, RS, HD, 0, T, lds, wave, nw, per, lane);
+    if (nt > 1) kv_glds(base, RS, HD, KT, T, lds + GSTAGE, wave, nw, per, lane);
+    if (MASK) {
+        for (int key = tid; key < nt * KT; key += nthr)
+            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+    }
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -272,30 +348,42 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = NEG, lsum = 0.f;
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int HD = p.H * 64;
-
-    unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long dt0 = __builtin_readcyclecounter();
-    const unsigned long long dbg_start = dt0;
-    kv_direct(base, RS, HD, 0, T, ldsK, ldsV, VP16, tid, nthr);
-    kbias_fill(kbias, p.mask, b, 0, T, tid);
-    __syncthreads();
-    // Q must be known-landed before the loop: the prefetch loads inside it sit under divergent guards, so a later wait on
-    // Q would have to be vmcnt(0) and would serialise the prefetch with the first MFMAs of every tile
+    // Q must be known-landed before the loop (a later wait on it would have to be vmcnt(0) in every tile); this also waits
+    // for tiles 0 and 1, which were issued in the same breath
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(qr[0]), "v"(qr[1]), "v"(qr[2]), "v"(qr[3]));
     dbg[0] = __builtin_readcyclecounter() - dt0;
-    for (int kv0 = 0; kv0 < T; kv0 += KT) {
-        const bool more = kv0 + KT < T;
-        KVRegs nxt;
+    // per-lane fragment addresses inside a stage (the swizzle terms depend only on the lane)
+    //   K: row = kb*32 + ql, chunk 2kk+h2 -> slot (2kk+h2) ^ k_swz(row); k_swz(kb*32 + ql) = k_swz(ql)
+    const int krow = ql * 128, ksw = k_swz(ql);
+    //   V (transposed read): row = k0 + (a16>>2) (+8), k0 = kb*32 + 16*s2 + 4*h2; chunk = db*4 + g16*2 + ((a16&3)>>1)
+    //   v_swz(row) depends on bit 1 of the row = bit 1 of (a16>>2) since k0 is a multiple of 4
+    const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
+    const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
+    int cur = 0;
+    for (int it = 0; it < nt; ++it) {
+        const int kv0 = it * KT;
         dt0 = __builtin_readcyclecounter();
-        if (more) kv_fetch(nxt, base, RS, HD, kv0 + KT, T, tid, nthr);     // in flight during this tile's MFMAs
+        // tile `it` landed (this wave's share; the barrier extends it to every wave's), tile it+1 may still be in flight
+        if (it > 0) wait_vm_dyn(it + 1 < nt ? per : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // stage of tile it-1 is free now (everyone is past that tile): refill it two tiles ahead
+        if (it + 2 < nt) {
+            int ns = cur + 2; ns = ns >= GNS ? ns - GNS : ns;
+            kv_glds(base, RS, HD, kv0 + 2 * KT, T, lds + ns * GSTAGE, wave, nw, per, lane);
+        }
+        const char* sk = lds + cur * GSTAGE;
+        const char* sv = sk + KT * 128;
+        if (DBG) { unsigned long long t1 = __builtin_readcyclecounter(); dbg[4] += t1 - dt0; dt0 = t1; }
 
         // all eight K fragments are requested before the first MFMA (one LDS round trip per tile instead of one per
         // MFMA), and the two key blocks' accumulation chains are interleaved so no MFMA waits on its predecessor
         const bool two = kv0 + 32 < T;              // else the second 32-key block is all padding (its P is exactly 0)
         bf16x8 kf[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kf[i] = ld_bf16x8(ldsK + ((i >> 2) * 32 + ql) * KP16 + (2 * (i & 3) + h2) * 16);
+        for (int i = 0; i < 8; ++i) kf[i] = ld_bf16x8(sk + (i >> 2) * 32 * 128 + krow + (((2 * (i & 3) + h2) ^ ksw) << 4));
         __builtin_amdgcn_sched_barrier(0);
         f32x16 s[2];
 #pragma unroll
@@ -314,7 +402,8 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
         }
         float alpha;
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[1] += t1 - dt0; dt0 = t1; }
-        softmax_tile<true>(s, kbias, h2, p.scale_log2e, m, lsum, alpha);
+        if (MASK) softmax_tile<true, true>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, alpha);
+        else softmax_tile<true, false>(s, nullptr, h2, p.scale_log2e, m, lsum, alpha, T - kv0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -326,16 +415,18 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + key;
+                    const unsigned long long idx = ((unsigned long long)bh_ * T + q) * T + key;
                     s[kb][r] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
                 }
         }
         {   // same for V: all transposed fragments first, then eight MFMAs alternating between the two d-blocks
             bf16x8 vf[8];
-            const char* vbase = ldsV + (4 * h2 + (a16 >> 2)) * VP16 + (16 * g16 + 4 * (a16 & 3)) * 2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)       // i = kb*4 + s2*2 + db
-                vf[i] = tr_frag(vbase + ((i >> 2) * 32 + 16 * ((i >> 1) & 1)) * VP16 + (i & 1) * 64, 8 * VP16);
+            for (int i = 0; i < 8; ++i) {     // i = kb*4 + s2*2 + db
+                const int roff = ((i >> 2) * 32 + 16 * ((i >> 1) & 1)) * 128 + vrow;
+                const int coff = ((((i & 1) * 4 + vch) ^ vsw) << 4) + vsub;
+                vf[i] = tr_frag(sv + roff + coff, 8 * 128);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -352,13 +443,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
             }
         }
         if (DBG) { asm volatile("" ::"v"(o[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[3] += t1 - dt0; dt0 = t1; }
-        if (more) {
-            __syncthreads();
-            kv_commit(nxt, ldsK, ldsV, VP16, tid, nthr);
-            kbias_fill(kbias, p.mask, b, kv0 + KT, T, tid);
-            __syncthreads();
-        }
-        if (DBG) { unsigned long long t1 = __builtin_readcyclecounter(); dbg[4] += t1 - dt0; dt0 = t1; }
+        cur = cur + 1 == GNS ? 0 : cur + 1;
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
@@ -377,13 +462,13 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_kernel(AttnParams p) {
     if (DBG && tid == 0) {
         unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.delta));
         const unsigned long long tend = __builtin_readcyclecounter();
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (qb_ == 0 && bh_ == 0) {
             for (int i = 0; i < 5; ++i) d[i] = dbg[i];
             d[5] = tend - dbg_start;
             d[6] = dbg_start;
         }
         // per-block record: start, end, HW_ID (wave/simd/cu/se), XCC_ID
-        const long blin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long blin = (long)bh_ * (gridDim.x / (((p.B * p.H + 7) / 8) * 8)) + qb_;
         d[8 + blin * 4 + 0] = dbg_start;
         d[8 + blin * 4 + 1] = tend;
         d[8 + blin * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
@@ -435,7 +520,9 @@ template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * QBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, kl = lane & 31;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    int qb_, bh_;
+    if (!attn_block_map(p, qb_, bh_)) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = p.T;
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
@@ -443,7 +530,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     const float* lse_g = p.lse + ((long)b * p.H + h) * T;
     const float* del_g = p.delta + ((long)b * p.H + h) * T;
     const int nthr = blockDim.x;
-    const int key = blockIdx.x * (nthr >> 1) + wave * 32 + kl;
+    const int key = qb_ * (nthr >> 1) + wave * 32 + kl;
     const bool kvalid = key < T;
     const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
 
@@ -575,7 +662,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
             float keep = 1.f;
             if (DROP) {
                 const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
-                const unsigned long long idx = ((unsigned long long)blockIdx.y * T + (q0 + qq)) * T + key;
+                const unsigned long long idx = ((unsigned long long)bh_ * T + (q0 + qq)) * T + key;
                 keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
             }
             pd[r] = pr * keep;                                   // dropped probabilities feed dV
@@ -625,13 +712,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     char* ldsV = lds + KT * KP16;
     float* kbias = reinterpret_cast<float*>(lds + 2 * KT * KP16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    int qb_, bh_;
+    if (!attn_block_map(p, qb_, bh_)) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = p.T;
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
     const int nthr = blockDim.x;
-    const int q = blockIdx.x * (nthr >> 1) + wave * 32 + ql;
+    const int q = qb_ * (nthr >> 1) + wave * 32 + ql;
     const bool qvalid = q < T;
 
     bf16x8 qr[4], gr[4];
@@ -700,7 +789,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
                 float keep = 1.f;
                 if (DROP) {
                     const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned long long idx = ((unsigned long long)blockIdx.y * T + q) * T + (kv0 + kk_);
+                    const unsigned long long idx = ((unsigned long long)bh_ * T + q) * T + (kv0 + kk_);
                     keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
                 }
                 ds[r] = pr * (dp[r] * keep - del) * scale;
@@ -772,16 +861,18 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
     SS_CHECK(out, "attention_fwd: null out");
     SS_CHECK(dtype == 1 || drop_p == 0.f, "attention_fwd: dropout is a training (bf16) feature");
+    SS_CHECK(dtype == 0 || !(key_mask || drop_p > 0.f) || T <= MAXT_BIAS, "attention_fwd: masked bf16 sequences are limited to %d keys", MAXT_BIAS);
     p.out = out; p.lse = lse;
     // one wave per 32 queries; a block holds up to 8 waves of the same (batch, head) so K/V tiles are staged once
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
-    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
+    dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
     if (dtype == 0)
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     else
-        if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+        if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+        else if (p.mask) hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
@@ -794,8 +885,8 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
     p.out = out; p.lse = lse; p.delta = reinterpret_cast<const float*>(dbg);
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
-    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+    dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_timeline");
     return 0;
 }
@@ -814,7 +905,7 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
                        (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
-    dim3 grid((unsigned)((q32 + nw - 1) / nw), (unsigned)(B * H));
+    dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
     if (p.drop_thresh) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(nw * 64), 0, s, p);
