@@ -547,17 +547,16 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
 //   transposed slab    [BKE k-rows][512 B]: 16-B slot s of k-row kr holds m-chunk s ^ ((kr & 3) << 2)
 // Requirements: bf16 operands, K % BKE == 0, 16-byte aligned contiguous extents (else the 128x128 kernel is used).
 // =================================================================================================================
-constexpr int LTHREADS = 512;
 
 template <int BKE> __device__ __forceinline__ int kc_swz(int r) { return BKE == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
 // issue the global->LDS copies of one operand slab (ROWS tile rows/cols x BKE k) for this wave
-template <int BKE, bool TRANS, int ROWS>
+template <int BKE, bool TRANS, int ROWS, int NW>
 __device__ __forceinline__ void glds_slab(const bf16_t* __restrict__ base, long ld, int row0, int lim, int k0, char* lds_slab,
                                           int wave, int lane) {
     constexpr int SLAB = ROWS * BKE * 2;
-    constexpr int NI = SLAB / 1024 / 8;              // 1-KiB pieces per wave
-    static_assert(NI >= 1, "slab too small for 8 waves");
+    constexpr int NI = SLAB / 1024 / NW;             // 1-KiB pieces per wave
+    static_assert(NI >= 1, "slab too small for the block's waves");
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int piece = wave * NI + i;
@@ -608,15 +607,15 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // TM x TN block tile, 8 waves as WM_ x WN_, each wave (TM/WM_) x (TN/WN_) = FM x FN MFMA 32x32 blocks.
 template <typename TO, bool TA, bool TB, int BKE, int NSTAGE, int TM, int TN, int WM_, int WN_, int MINW>
-__global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM_ * WN_ * 64, MINW) void gemm_large_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    static_assert(WM_ * WN_ == 8, "8 waves");
+    constexpr int NW = WM_ * WN_;
     constexpr int SLAB_A = TM * BKE * 2, SLAB_B = TN * BKE * 2, STAGE = SLAB_A + SLAB_B;
-    constexpr int LPS = SLAB_A / 1024 / 8 + SLAB_B / 1024 / 8;      // global_load_lds per wave per stage
+    constexpr int LPS = SLAB_A / 1024 / NW + SLAB_B / 1024 / NW;    // global_load_lds per wave per stage
     constexpr int KSTEPS = BKE / 16;
     constexpr int FM = TM / WM_ / 32, FN = TN / WN_ / 32;
-    static_assert(FN == 2, "the epilogue stages 64-column blocks");
-    static_assert(NSTAGE * STAGE >= 8 * EP_WAVE_FLOATS * 4, "operand ring doubles as epilogue scratch");
+    static_assert(FN % 2 == 0, "the epilogue stages 64-column blocks");
+    static_assert(NSTAGE * STAGE >= NW * EP_WAVE_FLOATS * 4, "operand ring doubles as epilogue scratch");
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
     unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,8 +643,8 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
         if (kt0 + s < kt1) {
-            glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, (kt0 + s) * BKE, lds + s * STAGE, wave, lane);
-            glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, (kt0 + s) * BKE, lds + s * STAGE + SLAB_A, wave, lane);
+            glds_slab<BKE, TA, TM, NW>(A, p.lda, m0, p.M, (kt0 + s) * BKE, lds + s * STAGE, wave, lane);
+            glds_slab<BKE, TB, TN, NW>(B, p.ldb, n0, p.N, (kt0 + s) * BKE, lds + s * STAGE + SLAB_A, wave, lane);
         }
     }
     int stage = 0;
@@ -663,8 +662,8 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
         const int nxt = kt + NSTAGE - 1;
         if (nxt < kt1) {
             int ns = stage + NSTAGE - 1; ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-            glds_slab<BKE, TA, TM>(A, p.lda, m0, p.M, nxt * BKE, lds + ns * STAGE, wave, lane);
-            glds_slab<BKE, TB, TN>(B, p.ldb, n0, p.N, nxt * BKE, lds + ns * STAGE + SLAB_A, wave, lane);
+            glds_slab<BKE, TA, TM, NW>(A, p.lda, m0, p.M, nxt * BKE, lds + ns * STAGE, wave, lane);
+            glds_slab<BKE, TB, TN, NW>(B, p.ldb, n0, p.N, nxt * BKE, lds + ns * STAGE + SLAB_A, wave, lane);
         }
         const char* sa = lds + stage * STAGE;
         const char* sb = sa + SLAB_A;
@@ -689,14 +688,18 @@ __global__ __launch_bounds__(LTHREADS, MINW) void gemm_large_kernel(GemmParams p
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int i = 0; i < FM; ++i) {        // rolled: one copy of the (large) epilogue body in the instruction stream
+    for (int c = 0; c < FM * (FN / 2); ++c) {      // rolled: one copy of the (large) epilogue body in the instruction stream
+        const int i = c / (FN / 2), jp = c % (FN / 2);
         f32x16 l = acc[0][0], r = acc[0][1];
 #pragma unroll
-        for (int ii = 1; ii < FM; ++ii)
-            if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
-        epilogue_block<TO>(p, l, r, wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * 64, lane, atomic, vec_ok, cs);
+        for (int cc = 1; cc < FM * (FN / 2); ++cc)
+            if (cc == c) { l = acc[cc / (FN / 2)][2 * (cc % (FN / 2))]; r = acc[cc / (FN / 2)][2 * (cc % (FN / 2)) + 1]; }
+        if (FN > 2 && jp == 0 && i > 0) { }       // (column sums are per 64-column block: flushed per block below)
+        float csb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        epilogue_block<TO>(p, l, r, wlds, m0 + wm * (FM * 32) + i * 32, n0 + wn * (FN * 32) + jp * 64, lane, atomic, vec_ok, FN == 2 ? cs : csb);
+        if (FN > 2) flush_colsum(p, csb, n0 + wn * (FN * 32) + jp * 64, lane);
     }
-    flush_colsum(p, cs, n0 + wn * 64, lane);
+    if (FN == 2) flush_colsum(p, cs, n0 + wn * 64, lane);
     if (p.accumulate == -1 && blockIdx.x == 0 && tid == 0) {     // debug timeline (cycle counter) of block 0 / wave 0
         unsigned long long* d = reinterpret_cast<unsigned long long*>(p.C);
         d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t2 - dbg_t1; d[2] = dbg_t3 - dbg_t2; d[3] = __builtin_readcyclecounter() - dbg_t3;
@@ -721,7 +724,7 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
     q.ksplit = (nk + splitk - 1) / splitk;
     const int z = (nk + q.ksplit - 1) / q.ksplit;
     q.nsplit = z;
-    hipLaunchKernelGGL(kern, dim3(tiles * z, 1, 1), dim3(LTHREADS), SMEM, stream, q);
+    hipLaunchKernelGGL(kern, dim3(tiles * z, 1, 1), dim3(WM_ * WN_ * 64), SMEM, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm(large)");
     return 0;
 }
@@ -732,7 +735,8 @@ int g_gemm_debug_skip_epilogue = 0;
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
 // 128x128 with BK=128, 256x128 with a 3-deep BK32 ring at 2 blocks/CU (563 vs 741 TFLOP/s aggregate), a persistent 256x256 kernel with
-// cross-tile prefetch, delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
+// cross-tile prefetch, four waves of 128x128 per block as the vendor library does (launch_large<..., 2, 2, 1>: 256 VGPR + 256 AGPR, no
+// spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
 // two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
 int g_gemm_variant = 0;
 
