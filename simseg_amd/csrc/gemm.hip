@@ -735,7 +735,9 @@ int g_gemm_debug_skip_epilogue = 0;
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
 // 128x128 with BK=128, 256x128 with a 3-deep BK32 ring at 2 blocks/CU (563 vs 741 TFLOP/s aggregate), a persistent 256x256 kernel with
-// cross-tile prefetch, four waves of 128x128 per block as the vendor library does (launch_large<..., 2, 2, 1>: 256 VGPR + 256 AGPR, no
+// cross-tile prefetch, an LDS-free epilogue on transposed accumulators (8-byte stores straight from registers: same time), a persistent
+// one-block-per-CU kernel that defers a tile's stores into the first eight K-slabs of the next tile (NT +1 %, NN slower), non-temporal
+// 16-byte output stores (same time; non-temporal 8-byte stores 30-50 % slower), four waves of 128x128 per block as the vendor library does (launch_large<..., 2, 2, 1>: 256 VGPR + 256 AGPR, no
 // spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
 // two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
 int g_gemm_variant = 0;
