@@ -314,6 +314,31 @@ def test_attention_bwd(ops, T):
         assert float(g[1, 9:, 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T", [1, 33, 64, 65, 129, 1025])
+def test_attention_edge_lengths(ops, T):
+    """Tile edges (one token, one over a 32 / 64 boundary, the 512^2 window) with a (batch x head) count that is not a multiple of
+    the 8 XCDs, forward in both dtypes and backward."""
+    B, H = 11, 1
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
+        qkv = _rand(B, T, 3 * H * 64, seed=T + 3, scale=1.3, dtype=dtype)
+        out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+        _close(out, _attn_ref(qkv, H, None, 0.125), tol, f"attention fwd T={T} {dtype}")
+    dout = _rand(B, T, H * 64, seed=T + 4, dtype=torch.bfloat16)
+    dqkv = ops.attention_bwd(qkv, out, dout, lse, H, None)
+    x = qkv.float().requires_grad_(True)
+    _attn_ref(x, H, None, 0.125).backward(dout.float())
+    _close(dqkv, x.grad, 2e-2, f"attention bwd T={T}")
+
+
+def test_attention_masked_length_limit(ops):
+    qkv = _rand(1, 1100, 3 * 64, seed=1, dtype=torch.bfloat16)
+    mask = torch.ones(1, 1100, dtype=torch.long, device="cuda")
+    with pytest.raises(RuntimeError, match="limited to"):
+        ops.attention_fwd(qkv, 1, mask)
+    out, _ = ops.attention_fwd(qkv.float(), 1, mask)         # the fp32 kernel has no such limit
+    _close(out, _attn_ref(qkv.float(), 1, mask, 0.125), 1e-5, "masked fp32 T=1100")
+
+
 def test_attention_dropout(ops):
     """Dropout on attention probabilities: mean preserved, same mask regenerated by the backward."""
     B, H, T = 2, 2, 77
