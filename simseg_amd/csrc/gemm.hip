@@ -741,6 +741,7 @@ int g_gemm_debug_skip_epilogue = 0;
 // spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
 // two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
 int g_gemm_variant = 0;
+int g_gemm_wgrad_large = 1;      // measured: 804 vs 660 TFLOP/s aggregate on the five wgrad shapes of the step (variant 7 turns it off)
 
 template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
@@ -752,6 +753,17 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // direct-to-LDS kernel wins for k-contiguous A from K >= 768 on when there is at least one tile per CU; split-K wgrad
     // (transposed A) and small problems stay on the 128x128 kernel (3 blocks/CU, more blocks to spread)
     const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if constexpr (TA && sizeof(TO) == 4) {
+        // split-K weight gradient (accumulating into a zero-filled fp32 output): the caller's slice count targets the 128x128
+        // kernel; for the 256x256 kernel pick the largest count that still fits ONE round of 256 blocks (a 288-block launch
+        // runs two rounds, the second 12 % full)
+        if ((v == 0 || v == 6) && v != 7 && big_ok && p.accumulate && splitk > 1 && p.M % 256 == 0 && p.N % 256 == 0 && tiles256 <= 128) {
+            const int sk = 256 / tiles256;
+            if (nk64 / sk >= 16 && (v == 6 || g_gemm_wgrad_large)) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, sk, s);
+        }
+        if (v == 6) v = 0;
+        if (v == 7) v = 1;
+    }
     if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 256) ? 2 : 1;
     if (!big_ok) v = 1;
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
