@@ -251,9 +251,18 @@ def main():
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
+    # The timed steps run the two towers on two HIP streams (their kernels share the GPU, so a per-kernel duration is not
+    # that kernel's own speed); the instrumented step runs them on ONE stream so that each launch is timed alone.
+    env_ts = os.environ.get("SIMSEG_AMD_TWO_STREAMS")
+    two_streams = (env_ts != "0") if env_ts is not None else world == 1      # the default of simseg/models/pipelines/clip.py
+    os.environ["SIMSEG_AMD_TWO_STREAMS"] = "0"
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()
+    if env_ts is None:
+        del os.environ["SIMSEG_AMD_TWO_STREAMS"]
+    else:
+        os.environ["SIMSEG_AMD_TWO_STREAMS"] = env_ts
     agg = {}
     for kind, fl, e0, e1 in ops.PROFILE:
         a = agg.setdefault(kind, [0, 0.0, 0.0])
@@ -293,16 +302,19 @@ def main():
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
+                       "tower_streams": 2 if two_streams else 1,
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic,
                          "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
-                         "flops_per_launch_avg": fl / cnt},
+                         "flops_per_launch_avg": fl / cnt,
+                         "measured": "one instrumented step with both towers on one stream (each launch alone on the GPU); the timed "
+                                     "steps overlap the two towers on two streams" if two_streams else "one instrumented step"},
             "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),
                            "whole_step_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
                            "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
-                           "gemm_time_share": round(gemm_sec / (elapsed / args.steps), 3),
+                           "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4)},
             "seg_eval": seg,

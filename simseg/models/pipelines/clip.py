@@ -4,6 +4,8 @@
 state-dict keys: image_encoder.model.model.* (timm names), text_encoder.model.model.* (HF names),
 image_projection.linear.weight, text_projection.linear.weight, loss.temperature."""
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -93,11 +95,51 @@ class CLIPModel(nn.Module):
             return self.forward_image_feature(batch["image"])
         if embeddings == "text":
             return self.forward_text_feature(batch["input_ids"], batch["attention_mask"])
-        img = self.forward_image_project(self.forward_image_feature(batch["image"]))
-        txt = self.forward_text_project(self.forward_text_feature(batch["input_ids"], batch["attention_mask"]), batch["attention_mask"])
+        image, ids, mask = batch["image"], batch["input_ids"], batch["attention_mask"]
+        if image.is_cuda and _two_streams_ok():
+            # The two towers are independent until the loss: the text tower runs on a second HIP stream so that its kernels
+            # fill the CUs the image tower's kernels leave idle (partial last rounds of the 256-CU tile grids, memory-bound
+            # LayerNorm / attention phases).  autograd replays each tower's backward on the stream its forward used.
+            main = torch.cuda.current_stream()
+            side = _side_stream(image.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
+            img = self.forward_image_project(self.forward_image_feature(image))
+            main.wait_stream(side)
+            txt.record_stream(main)
+        else:
+            img = self.forward_image_project(self.forward_image_feature(image))
+            txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
         if embeddings == "all":
             return [img, txt]
         return self.forward_loss(img, txt, ignore_mask=None)
+
+
+_SIDE = {}
+
+
+def _two_streams_ok():
+    """SIMSEG_AMD_TWO_STREAMS: 0 = never, 1 = always; default = unless gradients flow through torch DDP (its bucket hooks
+    synchronise the all-reduce with ONE stream - the one that produced the last gradient of a bucket - which is not a
+    guarantee this repo can test on a single-GPU box when gradients come from two streams)."""
+    env = os.environ.get("SIMSEG_AMD_TWO_STREAMS")
+    if env is not None:
+        return env != "0"
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    return not (multi and torch.is_grad_enabled())
+
+
+def _side_stream(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+        # text-tower gradients are produced on the side stream and accumulated on the parameters' stream: intended
+        # (autograd inserts the synchronisation), so its advisory warning is switched off
+        f = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if f is not None:
+            f(False)
+    return st
 
 
 class ImageEncoder(nn.Module):

@@ -292,3 +292,32 @@ def test_bf16_weight_copy_cache_coherence(golden, monkeypatch):
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict({k: v * 0 + 0.01 for k, v in sd.items()}, strict=False)
     assert torch.equal(towers._wt(w, torch.bfloat16), w.detach().bfloat16())
+
+
+def test_two_stream_towers_match_single_stream(golden, monkeypatch):
+    """The text tower on a second HIP stream (default outside DDP training) must not change anything: same loss trajectory and
+    gradients as the single-stream schedule over several optimizer steps (races would show up as drift)."""
+    from simseg_amd.optim import AdamW
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    g = golden("clip_train_ws1")
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", mode)
+        m = _build(golden)
+        m.eval()                                   # no dropout: the two schedules are comparable step by step
+        opt = AdamW(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(6):
+            opt.zero_grad(set_to_none=True)
+            loss = m(batch)[0]["nce_loss"]
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, {n: p.detach().clone() for n, p in m.named_parameters()})
+    l0, l1 = runs["0"][0], runs["1"][0]
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3 * max(abs(x) for x in l0), (l0, l1)
+    assert l0[-1] < l0[0]
+    worst = max(float((runs["0"][1][n] - runs["1"][1][n]).abs().max() / (runs["0"][1][n].abs().max() + 1e-12)) for n in runs["0"][1])
+    assert worst < 5e-2, worst                     # bf16 compute + fp32 atomics ordering; a race would be O(1)
