@@ -45,7 +45,7 @@ def run_vendor(kind, M, N, K, iters):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
-def run(kind, M, N, K, iters, out_f32=False):
+def run(kind, M, N, K, iters, out_f32=False, act=0, colsum=False):
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     ta, tb = kind == "tn", kind in ("nn", "tn")
@@ -58,6 +58,13 @@ def run(kind, M, N, K, iters, out_f32=False):
         kw.update(out=out, accumulate=True, splitk=max(1, min((K + 63) // 64, (1024 + tiles - 1) // tiles, 64)))
     elif out_f32:
         kw.update(out_dtype=torch.float32)
+    if kind != "tn":
+        if act == 1:        # forward fc1: bias + GELU, pre-activation saved
+            kw.update(act=1, bias=torch.zeros(N, device=dev), aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif act == 2:      # dgrad through fc2: multiply by GELU'(pre-activation)
+            kw.update(act=2, aux=torch.randn(M, N, device=dev, generator=g).bfloat16())
+        if colsum:
+            kw.update(colsum=torch.zeros(N, device=dev))
     for _ in range(3):
         ops.gemm(a, b, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -76,6 +83,8 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--act", type=int, default=0, help="1: bias+GELU with pre-activation save; 2: times GELU'(aux)")
+    ap.add_argument("--colsum", action="store_true", help="also accumulate column sums of the output (fused bias gradient)")
     ap.add_argument("--vendor", action="store_true", help="time torch.matmul (vendor BLAS) instead, as a yardstick")
     args = ap.parse_args()
     ops.set_gemm_variant(args.variant)
@@ -83,7 +92,7 @@ if __name__ == "__main__":
     for kind, M, N, K in SHAPES[args.shapes]:
         if args.only and kind != args.only:
             continue
-        ms, tf = (run_vendor if args.vendor else run)(kind, M, N, K, args.iters)
+        ms, tf = run_vendor(kind, M, N, K, args.iters) if args.vendor else run(kind, M, N, K, args.iters, act=args.act, colsum=args.colsum)
         tot_ms += ms; tot_fl += 2.0 * M * N * K
         print(f"{kind} M={M:6d} N={N:5d} K={K:6d}  {ms:8.3f} ms  {tf:8.1f} TFLOP/s", flush=True)
     print(f"sum {tot_ms:.3f} ms  -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
