@@ -23,7 +23,8 @@ const char* simseg_last_error(void);
 
 /* C[M,N] = epilogue(alpha * opA(A) . opB(B)).  transA=0: A is [M,K]; 1: [K,M].  transB=0: B is [N,K] (nn.Linear
  * weight layout); 1: [K,N].  Epilogue order: *rowscale[row], +bias[col], (save pre-activation to aux_out),
- * act (1 = erf-GELU, 2 = multiply by GELU'(aux)), dropout(p, seed), +residual.  row_group=G>0 writes row r to
+ * act (1 = erf-GELU, 2 = multiply by GELU'(aux); 3 = erf-GELU with aux_out receiving GELU'(pre-activation) instead of the
+ * pre-activation, 4 = multiply by aux: the training pair, no transcendental work in backward), dropout(p, seed), +residual.  row_group=G>0 writes row r to
  * (r/G)*(G+1)+1+r%G (ViT patch rows behind [cls]); res_mod reads the residual at row 1+r%G (pos_embed).
  * splitk>1 accumulates fp32 partials atomically into C (C must hold the value to accumulate onto).
  * colsum (optional, [N]) += column sums of the stored output: the bias gradient of the layer that produced C's input.

@@ -53,6 +53,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
     float g;
     return x * norm_cdf(x, g);
 }
+// y = gelu(x) and dy = gelu'(x) from one CDF / Gaussian evaluation (forward epilogue that stores the derivative for backward)
+__device__ __forceinline__ float gelu_erf_grad(float x, float& dy) {
+    float g;
+    const float cdf = norm_cdf(x, g);
+    dy = cdf + x * 0.39894228040143268f * g;
+    return x * cdf;
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
     float g;
     const float cdf = norm_cdf(x, g);

@@ -256,6 +256,16 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
                 Vec8<TO>::load(aux + o, a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(a[e]);
+            } else if (p.act == 3) {      // GELU whose DERIVATIVE is saved (the CDF and the Gaussian are in registers anyway)
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf_grad(v[e], d[e]);
+                if (aux_out) Vec8<TO>::store(aux_out + o, d);
+            } else if (p.act == 4) {      // times the saved derivative: no transcendental work in the backward epilogue
+                float a[8];
+                Vec8<TO>::load(aux + o, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= a[e];
             }
             if (p.drop_thresh) {
 #pragma unroll
@@ -288,6 +298,12 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
                     x = gelu_erf(x);
                 } else if (p.act == 2) {
                     x *= dgelu_erf(ld_out(aux + o + e));
+                } else if (p.act == 3) {
+                    float d;
+                    x = gelu_erf_grad(x, d);
+                    if (aux_out) st_out(aux_out + o + e, d);
+                } else if (p.act == 4) {
+                    x *= ld_out(aux + o + e);
                 }
                 if (p.drop_thresh) x = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + col + e, p.drop_thresh) ? x * p.drop_scale : 0.f;
                 if (p.residual) x += p.residual[ro + e];
@@ -815,7 +831,8 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f && !colsum),
              "simseg_gemm: split-K needs a plain fp32 accumulate epilogue");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "simseg_gemm: dropout p out of range");
-    SS_CHECK(act != 2 || aux, "simseg_gemm: act=2 needs aux");
+    SS_CHECK((act != 2 && act != 4) || aux, "simseg_gemm: act=2/4 needs aux");
+    SS_CHECK(act >= 0 && act <= 4, "simseg_gemm: act must be 0..4");
     SS_CHECK(!res_mod || row_group > 0, "simseg_gemm: res_mod needs row_group");
     GemmParams p;
     memset(&p, 0, sizeof(p));

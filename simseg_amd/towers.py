@@ -204,7 +204,7 @@ class ViTBlockFn(Function):
         x1 = ops.gemm(att.view(-1, D), pw_, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
         ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=save)
         pre = torch.empty(B * T, 4 * D, device=x.device, dtype=adt) if save else None
-        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=1, aux_out=pre)
+        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=3 if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
         y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
         ctx.adt, ctx.heads, ctx.dims = adt, heads, (B, T, D)
         if save:
@@ -229,7 +229,7 @@ class ViTBlockFn(Function):
         (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros(
             dy.device, (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
-        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=2, aux=pre, colsum=df1b)
+        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=4, aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
         dln2 = ops.gemm(dpre, f1w_, trans_b=True)
         df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
@@ -320,7 +320,7 @@ class BertLayerFn(Function):
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
         aa = a32 if adt == F32 else a16
         pre = torch.empty(B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
-        act = ops.gemm(aa, iw_, bias=ib.detach(), act=1, aux_out=pre)
+        act = ops.gemm(aa, iw_, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, _, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, save_stats=save)
         ctx.adt, ctx.heads, ctx.dims, ctx.drop = adt, heads, (B, L, D), (drop_p, seed)
@@ -341,7 +341,7 @@ class BertLayerFn(Function):
         (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros(
             dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
         ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy, dxsum=do2b, drop_seed=seed + 2, drop_p=p)
-        dpre = ops.gemm(d2, o2w_, trans_b=True, act=2, aux=pre, colsum=dib)
+        dpre = ops.gemm(d2, o2w_, trans_b=True, act=4, aux=pre, colsum=dib)
         do2w = _wgrad(d2, act, do2w_z) if need[18] else None
         da = ops.gemm(dpre, iw_, trans_b=True)
         diw = _wgrad(dpre, aa, diw_z) if need[16] else None

@@ -58,6 +58,13 @@ def test_gemm_f32_epilogues(ops):
     pre = torch.empty(M, N, device="cuda")
     _close(ops.gemm(a, b, bias=bias, act=1, aux_out=pre, residual=res), F.gelu(a @ b.T + bias) + res, 1e-5, "gelu+res")
     _close(pre, a @ b.T + bias, 1e-5, "saved pre-activation")
+    # training pair: act=3 stores GELU'(pre-activation), act=4 multiplies by the stored derivative
+    x32 = (a @ b.T + bias).detach().requires_grad_(True)
+    F.gelu(x32).backward(torch.ones_like(x32))
+    dact = torch.empty(M, N, device="cuda")
+    _close(ops.gemm(a, b, bias=bias, act=3, aux_out=dact), F.gelu(a @ b.T + bias), 1e-5, "gelu (derivative-saving)")
+    _close(dact, x32.grad, 1e-5, "saved GELU'")
+    _close(ops.gemm(a, b, act=4, aux=dact), (a @ b.T) * dact, 1e-5, "times saved derivative")
     # ViT token-row remap: rows of G patches land behind a [cls] row, residual = pos_embed[1 + r % G]
     G, Bn = 25, 12
     pos = _rand(G + 1, N, seed=6)
