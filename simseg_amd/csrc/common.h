@@ -83,13 +83,15 @@ __device__ __forceinline__ float wave_min(float v) {
     return v;
 }
 
-// counter-based RNG for dropout: one 32-bit hash per element index, reproducible in backward
+// counter-based RNG for dropout: one 32-bit hash per element index, reproducible in backward.  32-bit arithmetic only (the
+// 64-bit splitmix used first cost ~35 VALU instructions per element - more than the GELU it sat next to): the index and
+// seed halves are folded with odd multipliers, then the two-round "lowbias32" finaliser (bias < 0.11 bits / output bit).
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+    uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u + (uint32_t)seed + (uint32_t)(seed >> 32) * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x21F0AAADu;
+    x ^= x >> 15; x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
 }
 // keep-probability test: keep iff hash >= p * 2^32
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
