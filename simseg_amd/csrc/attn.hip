@@ -415,8 +415,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned long long idx = ((unsigned long long)bh_ * T + q) * T + key;
-                    s[kb][r] = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
+                    const unsigned idx = ((unsigned)bh_ * T + q) * T + key;                 // < 2^32: checked by the host
+                    s[kb][r] = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
                 }
         }
         {   // same for V: all transposed fragments first, then eight MFMAs alternating between the two d-blocks
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
             float keep = 1.f;
             if (DROP) {
                 const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
-                const unsigned long long idx = ((unsigned long long)bh_ * T + (q0 + qq)) * T + key;
-                keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                const unsigned idx = ((unsigned)bh_ * T + (q0 + qq)) * T + key;
+                keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
             }
             pd[r] = pr * keep;                                   // dropped probabilities feed dV
             ds[r] = pr * (dp[r] * keep - dq_) * scale;          // dS feeds dK
@@ -789,8 +789,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
                 float keep = 1.f;
                 if (DROP) {
                     const int kk_ = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned long long idx = ((unsigned long long)bh_ * T + q) * T + (kv0 + kk_);
-                    keep = dropout_keep(p.drop_seed, idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                    const unsigned idx = ((unsigned)bh_ * T + q) * T + (kv0 + kk_);
+                    keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
                 }
                 ds[r] = pr * (dp[r] * keep - del) * scale;
             }
@@ -843,6 +843,7 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
     SS_CHECK(B > 0 && T > 0 && H > 0 && B * H < 65536 * 16, "attention: bad shape");
     SS_CHECK(((uintptr_t)qkv % 16) == 0, "attention: qkv must be 16-byte aligned");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention: dropout p out of range");
+    SS_CHECK(drop_p == 0.f || (double)B * H * T * T < 4294967296.0, "attention: dropout needs B*H*T*T < 2^32");
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = (const long*)mask; p.B = (int)B; p.T = (int)T; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;

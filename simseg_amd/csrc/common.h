@@ -93,6 +93,16 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
     x ^= x >> 15;
     return x;
 }
+// the same hash for an index known to fit 32 bits, with the seed folded once per kernel (seed_fold): one multiply-add
+// plus the finaliser per element and no 64-bit temporaries (the attention backward kernels have no registers to spare)
+__device__ __forceinline__ uint32_t seed_fold(uint64_t seed) { return (uint32_t)seed + (uint32_t)(seed >> 32) * 0xC2B2AE3Du; }
+__device__ __forceinline__ bool dropout_keep32(uint32_t seedf, uint32_t idx, uint32_t thresh) {
+    uint32_t x = idx * 0x9E3779B1u + seedf;
+    x ^= x >> 16; x *= 0x21F0AAADu;
+    x ^= x >> 15; x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x >= thresh;
+}
 // keep-probability test: keep iff hash >= p * 2^32
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
     return hash_u32(seed, idx) >= thresh;
