@@ -822,20 +822,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     }
 }
 
-// Waves (= 32-query tiles) per block.  The kernels hold 2-3 waves per SIMD (register bound), i.e. 8-12 waves per CU:
-// blocks of 3, 4 or 6 waves tile that exactly, while a 7- or 8-wave block would leave almost half the CU's wave slots
-// empty.  Among those, pick the size that wastes the fewest wave slots on padding (ties: the larger block, which
-// re-stages K/V less often).
-int attn_waves_per_block(int q32) {
-    if (q32 <= 4) return q32;
-    int best = 4, best_pad = ((q32 + 3) / 4) * 4 - q32;
-    const int cand[2] = {6, 3};
-    for (int c : cand) {       // measured (profiles/r1_kernel_roofline.txt): fewest padded slots wins; 6-wave blocks only on a tie
-        const int pad = ((q32 + c - 1) / c) * c - q32;
-        if (pad < best_pad || (pad == best_pad && c > best)) { best = c; best_pad = pad; }
-    }
-    return best;
-}
+// Waves (= 32-query tiles) per block.  The kernels hold 2-3 waves per SIMD (register bound), i.e. 8-12 waves per CU, which
+// 4-wave blocks tile exactly.  Measured on ViT-B (profiles/r1_kernel_roofline.txt): 4-wave blocks win at T = 197 (7 row tiles,
+// one padded slot) AND at T = 1025 (33 row tiles: 0.109 ms against 0.136 ms for 3-wave blocks without padding and 0.164 ms
+// for 6-wave blocks) - fewer waves per barrier and per staged K/V tile beat a perfectly filled last block.
+int attn_waves_per_block(int q32) { return q32 <= 4 ? q32 : 4; }
 
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
                 uint64_t seed, float drop_p) {

@@ -4,15 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simseg_amd.lib import call, ptr, stream
 
 
-def waves(q32):
-    if q32 <= 4:
-        return q32
-    best, bw = None, None
-    for w in (4, 6, 3):
-        pad = (q32 + w - 1) // w * w - q32
-        if best is None or pad < best or (pad == best and w > bw):
-            best, bw = pad, w
-    return bw
+def waves(q32):          # attn_waves_per_block in simseg_amd/csrc/attn.hip
+    return q32 if q32 <= 4 else 4
 
 
 for (B, T, H) in ((1, 197, 1), (512, 197, 12), (16, 1025, 12)):
