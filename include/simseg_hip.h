@@ -59,7 +59,11 @@ int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
  * optional) are ACCUMULATED. */
 int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x, const float* mean,
                          const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
-                         float* dbeta, float* dxsum, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p, void* stream);
+                         float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p,
+                         void* stream);
+/* Size (in floats) of the `partials` scratch of simseg_layernorm_bwd: per-block column sums, folded by a second small kernel
+ * (one add per column) instead of one atomic per column per block.  partials = NULL selects the atomic path. */
+int64_t simseg_layernorm_bwd_partials(int64_t rows, int64_t D);
 
 /* out[n] += sum_r in[r,n]  (bias / embedding-table gradients). */
 int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream);

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx32,
                                                      bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dxsum, int rows, int D,
+                                                     float* __restrict__ dbeta, float* __restrict__ dxsum, float* __restrict__ partials,
+                                                     int rows, int D,
                                                      unsigned long long drop_seed, unsigned int drop_thresh, float drop_scale) {
     __shared__ float red[3][1024];   // [dgamma|dbeta|dxsum][wave * 256 + lane * 4 + j]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,17 +105,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float g[MAXC][4], xh[MAXC][4];
+        float g[MAXC][4], xh[MAXC][4], rr[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[i][j] = 0.f;
             if (c < nch) {
                 const long o = (long)row * D + c * 4;
                 float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4];
                 if (dy16) load4<bf16_t>(dy16 + o, a);
                 if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
                 load4<float>(x + o, xv);
+                if (dres) load4<float>(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -133,10 +137,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             const int c = lane + 64 * i;
             if (c < nch) {
                 const long o = (long)row * D + c * 4;
-                float out[4], r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (dres) load4<float>(dres + o, r);
+                float out[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + r[j];
+                for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + rr[i][j];
                 if (dx32) store4<float>(dx32 + o, out);
                 if (drop_thresh) {
 #pragma unroll
@@ -167,12 +170,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             for (int j = 0; j < 4; ++j) {
                 float sg = 0.f, sb = 0.f, ss = 0.f;
                 for (int w = 0; w < 4; ++w) { sg += red[0][w * 256 + lane * 4 + j]; sb += red[1][w * 256 + lane * 4 + j]; ss += red[2][w * 256 + lane * 4 + j]; }
-                atomicAdd(dgamma + c * 4 + j, sg);
-                atomicAdd(dbeta + c * 4 + j, sb);
-                if (dxsum) atomicAdd(dxsum + c * 4 + j, ss);
+                if (partials) {      // [block][3][D] plain stores; ln_bwd_reduce_kernel folds the blocks (1 atomic per column in total)
+                    float* pb = partials + (long)blockIdx.x * 3 * D + c * 4 + j;
+                    pb[0] = sg; pb[D] = sb; pb[2 * D] = ss;
+                } else {
+                    atomicAdd(dgamma + c * 4 + j, sg);
+                    atomicAdd(dbeta + c * 4 + j, sb);
+                    if (dxsum) atomicAdd(dxsum + c * 4 + j, ss);
+                }
             }
         }
     }
+}
+
+// Second stage of the LayerNorm backward column reductions.  With one atomic per column per block the 1024 blocks of a
+// [100864, 768] launch sent 2.4 M atomics to 2304 addresses at the same moment (they finish together): 93 of the kernel's 307 us.
+// Blocks now store their partial sums and this kernel folds them: thread = one of the 3*D columns, coalesced over columns.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int D, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dxsum) {
+    const int col = blockIdx.x * 256 + threadIdx.x;          // 0 .. 3*D
+    if (col >= 3 * D) return;
+    float* dst = col < D ? dgamma + col : (col < 2 * D ? dbeta + (col - D) : (dxsum ? dxsum + (col - 2 * D) : nullptr));
+    if (!dst) return;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;   // partial rows of this y-slice: 32 independent loads in flight per thread
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += partials[(long)b * 3 * D + col];
+        s1 += partials[(long)(b + 1) * 3 * D + col];
+        s2 += partials[(long)(b + 2) * 3 * D + col];
+        s3 += partials[(long)(b + 3) * 3 * D + col];
+    }
+    for (; b < b1; ++b) s0 += partials[(long)b * 3 * D + col];
+    if (b1 > b0) atomicAdd(dst, (s0 + s1) + (s2 + s3));      // gridDim.y (32) adds per column instead of one per row-block (1024)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -450,8 +481,8 @@ extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const fl
 
 extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x,
                                     const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
-                                    float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t D, uint64_t drop_seed,
-                                    float drop_p, void* stream) {
+                                    float* dgamma, float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D,
+                                    uint64_t drop_seed, float drop_p, void* stream) {
     SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
@@ -462,16 +493,22 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     const int nc = (int)((D + 255) / 256);
 #define LN_BWD_LAUNCH(C)                                                                                                              \
     hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, x, mean, rstd, gamma, \
-                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
+                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
     if (nc <= 1) LN_BWD_LAUNCH(1);
     else if (nc == 2) LN_BWD_LAUNCH(2);
     else if (nc == 3) LN_BWD_LAUNCH(3);
     else if (nc == 4) LN_BWD_LAUNCH(4);
     else LN_BWD_LAUNCH(8);
 #undef LN_BWD_LAUNCH
+    if (partials)
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * D + 255) / 256), 32), dim3(256), 0, STREAM, partials, grid, (int)D,
+                           dgamma, dbeta, dxsum);
     SS_LAUNCH_CHECK("layernorm_bwd");
     return 0;
 }
+
+/* floats the caller must provide as `partials` for a launch over `rows` rows of width D */
+extern "C" int64_t simseg_layernorm_bwd_partials(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, 1024) * 3 * D; }
 
 extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream) {
     SS_CHECK(in && out, "colsum: null pointer");

@@ -18,7 +18,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(const char\*|int)\s+(simseg_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const char\*|int64_t|int)\s+(simseg_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         alist = []
         if args and args != "void":
@@ -29,7 +29,7 @@ def parse_header(path=HEADER):
                 else:
                     ty, nm = a.rsplit(" ", 1)
                     alist.append((_CT[ty], nm))
-        out[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, alist)
+        out[name] = (ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int), alist)
     return out
 
 
@@ -61,6 +61,11 @@ def ptr(t):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def raw(name, *args):
+    """Entry points that return a value (sizes), not a status."""
+    return getattr(load(), name)(*args)
 
 
 def call(name, *args):

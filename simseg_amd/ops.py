@@ -2,7 +2,7 @@
 all arithmetic runs in libsimseg_hip.so.  No autograd here (see autograd.py) and no CPU fallback."""
 import torch
 
-from .lib import call, ptr, require_gpu, stream
+from .lib import call, ptr, require_gpu, stream, raw
 
 F32, BF16 = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -83,8 +83,9 @@ def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dre
     rows = x.numel() // D
     dx32 = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_f32 else None
     dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    partials = torch.empty(raw("simseg_layernorm_bwd_partials", rows, D), device=x.device, dtype=torch.float32)
     call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
-         ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), rows, D, int(drop_seed), float(drop_p), stream())
+         ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(partials), rows, D, int(drop_seed), float(drop_p), stream())
     return dx32, dx16
 
 
