@@ -96,11 +96,13 @@ def cpu_baseline(img, L, budget_s=20.0):
             "sample": f"{n} fwd+bwd+AdamW steps of {B} pairs (ViT-B/16 @{img}, BERT-base L={L}) with the torch-fp32 oracle"}
 
 
-def seg_eval_bench(dev, world, dtype, windows=64, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
+def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
     """Zero-shot segmentation GPU stage (BASELINE configs[3] shape): ViT-B on 512x512 windows -> projection -> LoDA pooled
     embedding + dense patch x class-text similarity map for all `classes` + candidate selection, masks, 7x7 morphology,
     resize/argmax and IoU histograms on the device (tools/seg_evaluation.py:99-170 without the CPU CRF stage).  Independent
-    windows: sharded over ranks, no collective on the data path (one all-reduce of the [3,C] histograms at the end)."""
+    windows: sharded over ranks, no collective on the data path (one all-reduce of the [3,C] histograms at the end).
+    Batch = 21 source images of 3 windows: 63 x 1025 tokens = 252.2 row panels of 256, i.e. the GEMM tile grids (759 / 2277 /
+    3036 tiles) fill their last round of 256 CUs to 97-99 %; 64 windows would be 257 panels = 3.01 rounds for N = 768."""
     from simseg_amd.heads import patch_text_similarity
     from simseg_amd import ops
     from simseg.models import PIPELINE

@@ -18,6 +18,8 @@ SHAPES = {
         ("tn", 2304, 768, MV), ("tn", 768, 768, MV), ("tn", 3072, 768, MV), ("tn", 768, 3072, MV), ("tn", 3072, 768, MB),
     ],
     "quick": [("nt", MV, 3072, 768), ("nt", MV, 768, 3072), ("nn", MV, 768, 3072), ("tn", 3072, 768, MV)],
+    "nsplit": [("nt", MV, 2304, 768), ("nt", MV, 1152, 768), ("nt", MV, 3072, 768), ("nt", MV, 1536, 768), ("nt", MV, 1024, 768),
+               ("nn", MV, 3072, 768), ("nn", MV, 1536, 768), ("nt", MV, 768, 768), ("nt", MV, 512, 768), ("nt", MV, 256, 768)],
     "square": [("nt", 4096, 4096, 4096), ("nt", 8192, 8192, 8192)],
     "msweep": [("nt", m, 768, 128) for m in (256, 4096, 16384, 65536, MV)] + [("nt", m, 768, 768) for m in (256, 4096, 16384, 65536, MV)],
     "ksweep": [("nt", MV, 768, k) for k in (128, 256, 512, 768, 1536, 3072, 6144)],
