@@ -754,7 +754,8 @@ int g_gemm_debug_skip_epilogue = 0;
 // cross-tile prefetch, an LDS-free epilogue on transposed accumulators (8-byte stores straight from registers: same time), a persistent
 // one-block-per-CU kernel that defers a tile's stores into the first eight K-slabs of the next tile (NT +1 %, NN slower), non-temporal
 // 16-byte output stores (same time; non-temporal 8-byte stores 30-50 % slower), four waves of 128x128 per block as the vendor library does (launch_large<..., 2, 2, 1>: 256 VGPR + 256 AGPR, no
-// spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
+// spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), 256x128 tiles on four 128x64 waves at two
+// blocks per CU so that one block's epilogue overlaps the other's K loop (launch_large<..., 32, 2|3, 256, 128, 2, 2, 2>: 630 vs 670), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
 // two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
 int g_gemm_variant = 0;
 int g_gemm_wgrad_large = 1;      // measured: 804 vs 660 TFLOP/s aggregate on the five wgrad shapes of the step (variant 7 turns it off)
