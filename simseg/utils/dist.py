@@ -11,7 +11,7 @@ from . import logger
 from .context import ENV
 
 __all__ = ["all_gather", "all_gather_group", "all_reduce", "broadcast", "barrier", "GatherLayer", "concat_all_gather",
-           "generate_local_groups", "all_gather_object"]
+           "generate_local_groups", "all_gather_object", "all_gather_with_grad", "broadcast_list", "broadcast_object_list"]
 
 
 def _on():
@@ -60,6 +60,39 @@ def all_gather_object(object_list, obj, group=None, *_unused):
         object_list[0] = obj
         return
     dist.all_gather_object(object_list, obj, group=group)
+
+
+class all_gather_with_grad(torch.autograd.Function):
+    """dist.py:28-40: tuple of every rank's tensor; the backward keeps the gradient of this rank's slot only (no reduction:
+    the older of the reference's two differentiable gathers - NCE uses GatherLayer)."""
+
+    @staticmethod
+    def forward(ctx, tensor):
+        if not _on():
+            return (tensor.clone(),)
+        out = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, tensor.contiguous())
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return grads[dist.get_rank() if _on() else 0].clone()
+
+
+def broadcast_list(x, name=None, src=0):
+    """dist.py:124-139: a list of numbers through a device tensor; returns the source rank's list (not in place)."""
+    if not isinstance(x, list):
+        raise AssertionError("broadcast_list only takes list as input.")
+    t = torch.tensor(x, device=ENV.device if ENV.device is not None else "cpu")
+    broadcast(t, src=src)
+    return t.tolist()
+
+
+def broadcast_object_list(object_list, src=0, group=None):
+    """dist.py:225-290 re-implements torch's object broadcast; torch's own does the job (objects pickled through tensors on the
+    current device for RCCL)."""
+    if _on():
+        dist.broadcast_object_list(object_list, src=src, group=group)
 
 
 @torch.no_grad()

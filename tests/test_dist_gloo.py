@@ -50,6 +50,17 @@ def _worker(rank, world, port, q):
     sub, sub_rank = generate_local_groups(1)
     res["sub"] = (dist.get_world_size(sub), sub_rank)
     res["cat"] = concat_all_gather(torch.full((2,), float(rank))).tolist()
+    # the reference's other helpers (dist.py:28-40, 124-139, 225-290)
+    from simseg.utils.dist import all_gather_with_grad, broadcast_list, broadcast_object_list
+    ENV.device = torch.device("cpu")
+    t = torch.full((3,), float(rank + 1), requires_grad=True)
+    parts = all_gather_with_grad.apply(t)
+    sum(float(i + 1) * p.sum() for i, p in enumerate(parts)).backward()
+    res["awg"] = ([p[0].item() for p in parts], t.grad.tolist())
+    res["blist"] = broadcast_list([rank, 7 + rank], src=1)
+    objs = [{"rank": rank}, "x" * (rank + 1)]
+    broadcast_object_list(objs, src=0)
+    res["bobj"] = objs
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -76,3 +87,6 @@ def test_gather_layer_matches_reference_two_ranks(world):
         np.testing.assert_allclose(o["gt"], o["want_gt"], rtol=1e-4)
         assert o["sub"] == (1, 0)
         assert o["cat"] == [0.0, 0.0, 1.0, 1.0]
+        assert o["awg"] == ([1.0, 2.0], [float(r + 1)] * 3)          # gradient of this rank's slot only
+        assert o["blist"] == [1, 8]
+        assert o["bobj"] == [{"rank": 0}, "x"]
