@@ -179,6 +179,42 @@ def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
             "gemm_tflops_fp32": round(2 * 2.0 * m * n * d / dt / 1e12, 1), "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
 
 
+def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250):
+    """Encoder-inclusive retrieval eval (README.md:185 / tools/retrieval_evaluation.py:60-100 at MSCOCO-5k shape): 5000 images at
+    288^2 and 25000 captions of 25 tokens through the towers (bf16), then recalls in both directions.  Synthetic inputs,
+    random weights; returns wall time and rates."""
+    from simseg.models import PIPELINE
+    from simseg_amd.heads import retrieval_recalls
+    os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+    cfg, build = build_model("vit_base_patch16_224_in21k", 768, img)
+    torch.manual_seed(11)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).eval()
+    tb = ib * cap_per_img
+    batch = synthetic_batch(tb, img, L, 30522, 77, dev)
+    batch["image"] = batch["image"][:ib].contiguous()
+
+    def run():
+        ie, te = [], []
+        with torch.no_grad():
+            for _ in range(n_img // ib):
+                a, b = model(batch, embeddings="all")
+                ie.append(a); te.append(b)
+            ie, te = torch.cat(ie).float(), torch.cat(te).float()
+            gi = torch.arange(ie.shape[0], device=dev)
+            gt = torch.arange(te.shape[0], device=dev) // cap_per_img
+            return retrieval_recalls(ie, gi, te, gt), retrieval_recalls(te, gt, ie, gi)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del model
+    return {"shape": f"{n_img} images @{img}^2 + {n_img * cap_per_img} captions L={L}, bf16 towers", "seconds": round(dt, 3),
+            "images_per_s": round(n_img / dt, 1), "captions_per_s": round(n_img * cap_per_img / dt, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +314,10 @@ def main():
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"seg eval stage: {seg}")
     retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
+    if retr is not None:
+        retr["encoder_inclusive"] = retrieval_encode_bench(dev)
+        os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+        log(f"retrieval eval: {retr}")
 
     if rank == 0:
         n_patches = (args.img // 16) ** 2
