@@ -310,7 +310,10 @@ def main():
     torch.cuda.empty_cache()
     seg = None
     if not args.no_seg:
-        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16")}
+        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16"),
+               # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
+               "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
+               "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"seg eval stage: {seg}")
     retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
