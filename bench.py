@@ -159,6 +159,49 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
             "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
 
 
+def seg_latency_bench(dev, dtype, img, classes, tag, dim, reps=50):
+    """One image per call, as the reference's tool runs (tools/seg_evaluation.py:99-170, batch size 1): towers -> projection ->
+    similarity map -> device post-processing.  At this size the forward is ~150 launches of a few microseconds, so the same
+    pipeline is also captured once into a hipGraph (simseg_amd/graph.py) and replayed.  Returns ms per image, both ways."""
+    from simseg.models import PIPELINE
+    from simseg_amd import ops, segpost
+    from simseg_amd.graph import GraphedCall
+    from simseg_amd.heads import patch_text_similarity
+    os.environ["SIMSEG_AMD_COMPUTE"] = dtype
+    cfg, build = build_model(tag, dim, img)
+    torch.manual_seed(7)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(classes, 512, generator=g), dim=-1).to(dev)
+    image = torch.randn(1, 3, img, img, generator=g).to(dev)
+    labels = torch.randint(0, classes, (1, img, img), generator=g, dtype=torch.int64).to(torch.uint8).to(dev)
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+
+    def pipeline(im):
+        feats = model.forward_image_feature(im)
+        pooled = model.forward_image_project(feats)
+        sim = patch_text_similarity(model.image_projection(feats), text, compute_dtype=cdt)
+        out = segpost.segment(sim, ops.gemm(pooled.float(), text), labels, img // 16, 10, want_pred=True)
+        return out["pred"], out["hist"]
+
+    def timed(fn):
+        for _ in range(5):
+            fn(image)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(image)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    with torch.no_grad():
+        eager = timed(pipeline)
+    graphed = timed(GraphedCall(pipeline, image))
+    del model
+    return {"dtype": dtype, "encoder": tag, "input": img, "classes": classes, "eager_ms_per_image": round(eager, 3),
+            "hipgraph_ms_per_image": round(graphed, 3), "images_per_s_hipgraph": round(1e3 / graphed, 1)}
+
+
 def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
     """BASELINE configs[4] shape: R@1/5/10 in both directions over the full 5k x 25k similarity matrix (fp32 MFMA GEMM +
     first-match-rank kernel instead of the reference's argsort + int64 gid gather, hooks/utils.py:36-42)."""
@@ -314,6 +357,10 @@ def main():
                # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
                "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
                "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
+        if rank == 0:         # single-image latency (the reference tool's batch size), eager launches vs one hipGraph replay
+            seg["latency_batch1"] = [seg_latency_bench(dev, "fp32", 288, 21, "vit_small_patch16_224_in21k", 384),
+                                     seg_latency_bench(dev, "fp32", 512, 171, "vit_base_patch16_224_in21k", 768),
+                                     seg_latency_bench(dev, "bf16", 512, 171, "vit_base_patch16_224_in21k", 768)]
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"seg eval stage: {seg}")
     retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None

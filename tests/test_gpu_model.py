@@ -321,3 +321,32 @@ def test_two_stream_towers_match_single_stream(golden, monkeypatch):
     assert l0[-1] < l0[0]
     worst = max(float((runs["0"][1][n] - runs["1"][1][n]).abs().max() / (runs["0"][1][n].abs().max() + 1e-12)) for n in runs["0"][1])
     assert worst < 5e-2, worst                     # bf16 compute + fp32 atomics ordering; a race would be O(1)
+
+
+def test_graphed_forward_matches_eager(golden, monkeypatch):
+    """hipGraph replay of the per-image segmentation forward (towers -> projection -> similarity map -> candidate selection)
+    returns what the eager launches return, for inputs it was not captured with."""
+    from simseg_amd.graph import GraphedCall
+    from simseg_amd.heads import patch_text_similarity
+    from simseg_amd import ops
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+        m = _build(golden).eval()
+        g = torch.Generator().manual_seed(3)
+        text = torch.nn.functional.normalize(torch.randn(21, 512, generator=g), dim=-1).cuda()
+
+        def pipeline(image):
+            feats = m.forward_image_feature(image)
+            pooled = m.forward_image_project(feats)
+            sim = patch_text_similarity(m.image_projection(feats), text)
+            idx, score, thr = ops.seg_select(ops.gemm(pooled.float(), text), 10, 5)
+            return sim, idx, score
+
+        imgs = [torch.randn(1, 3, 96, 96, generator=g).cuda() for _ in range(3)]
+        gc = GraphedCall(pipeline, imgs[0])
+        for im in imgs[1:]:
+            with torch.no_grad():
+                want = [t.clone() for t in pipeline(im)]
+            got = gc(im)
+            torch.cuda.synchronize()
+            assert _maxerr(got[0], want[0]) < 1e-6 and torch.equal(got[1], want[1]) and _maxerr(got[2], want[2]) < 1e-6, mode
