@@ -86,7 +86,10 @@ int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, const float* 
  * (pipelines/clip.py:87-93,111-120).  idx[B,k,P] and norm[B] are saved for the backward.  normalize=0 returns the
  * pooled vector itself (TopKPooling used on its own). */
 int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
-                                int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
+                                float* scratch, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
+/* floats of the optional `scratch`: with it the tokens of an image are scanned by 32 blocks in parallel and merged (same
+ * result, ties included) - for small batches, where one block per image leaves the GPU empty; NULL = one block per image. */
+int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 

@@ -138,7 +138,11 @@ def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8, normalize=True):
     emb = torch.empty(B, P, device=tok.device, dtype=torch.float32)
     idx = torch.empty(B, k, P, device=tok.device, dtype=torch.int32)
     norm = torch.empty(B, device=tok.device, dtype=torch.float32)
-    call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), B, N, P, int(k), float(eps), int(normalize), stream())
+    scratch = None
+    if B < 64 and N >= 256:          # few images: scan token slices in parallel (one block per image would leave the GPU empty)
+        scratch = torch.empty(raw("simseg_topk_pool_scratch", B, P, int(k)), device=tok.device, dtype=torch.float32)
+    call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), ptr(scratch), B, N, P, int(k),
+         float(eps), int(normalize), stream())
     return emb, idx, norm
 
 

@@ -226,6 +226,23 @@ def test_bert_embed(ops):
     _close(dword, refw, 1e-5, "bert embed bwd")
 
 
+def test_topk_pool_sliced_equals_single_pass(ops):
+    """Small batches scan token slices in parallel and merge; the result - selected indices included, with the many ties of
+    bf16 data - is the single-pass kernel's."""
+    from simseg_amd.lib import call, ptr, raw, stream
+    for dtype, (B, N, P, k) in ((torch.bfloat16, (3, 1024, 512, 5)), (torch.float32, (1, 333, 128, 3)), (torch.bfloat16, (2, 300, 64, 1))):
+        tok = (_rand(B, N, P, seed=N, dtype=torch.float32) * 2).round().div(2).to(dtype)        # coarse values: ties everywhere
+        mask = None
+        outs = []
+        for sliced in (False, True):
+            emb = torch.empty(B, P, device="cuda"); idx = torch.empty(B, k, P, device="cuda", dtype=torch.int32); norm = torch.empty(B, device="cuda")
+            scratch = torch.empty(raw("simseg_topk_pool_scratch", B, P, k), device="cuda") if sliced else None
+            call("simseg_topk_pool_l2norm_fwd", ptr(tok), 0 if dtype == torch.float32 else 1, None, ptr(emb), ptr(idx), ptr(norm), ptr(scratch),
+                 B, N, P, k, 1e-8, 1, stream())
+            outs.append((emb, idx, norm))
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_topk_pool_l2norm(ops, golden, dtype):
     from conftest import tt
