@@ -138,9 +138,10 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        last = step()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    visited = int((last[2]["cand_idx"] >= 0).sum())
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(hist)               # the only exchange of the seg path - intersect / area histograms, once
@@ -150,10 +151,12 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     fl = 12 * (24 * t * dim * dim + 4 * t * t * dim) + 2 * n_patches * 768 * dim + 2 * 2 * n_patches * dim * 512 + 2 * n_patches * 512 * classes
     wps = world * windows * steps / float(el)
     post_ms = post_ev[0].elapsed_time(post_ev[1])
-    # algorithmic bytes of the post stage per window: 5 candidate maps of (img x img) bytes are written once, dilated and
-    # eroded (read + write each), read again with the label map for the argmax / IoU pass
-    post_bytes = windows * img * img * (5 + 4 * 5 + 5 + 1)
-    return {"post_ms_per_step": round(post_ms, 3), "post_GBps": round(post_bytes / post_ms / 1e6, 1),
+    # algorithmic bytes of the post stage: every VISITED candidate map (img x img bytes) is written once, read and written by the
+    # fused dilate+erode, and read again for the argmax / IoU pass; the label map is read once per window.  (All five slots are
+    # read by the argmax pass as the reference's temp_pred[...] stack would be: counted for visited ones only.)
+    post_bytes = img * img * (4 * visited + windows)
+    return {"post_ms_per_step": round(post_ms, 3), "post_visited_candidates_per_window": round(visited / windows, 2),
+            "post_GBps": round(post_bytes / post_ms / 1e6, 1),
             "post_frac_of_hbm_peak": round(post_bytes / post_ms / 1e6 / 8000.0, 4), "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
             "classes": classes, "windows_per_step_per_gpu": windows, "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
             "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}

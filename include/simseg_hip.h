@@ -164,6 +164,10 @@ int simseg_seg_masks(const float* sim, const int* cand_idx, float* prob, void* m
 /* cv2.dilate / cv2.erode with a 7x7 ones kernel, ONE iteration (the third positional argument in :156-157 is `dst`, not
  * `iterations`), default border (never wins) on byte images [M,H,W]; erode = 0 dilate, 1 erode.  out must not alias in. */
 int simseg_morph7(const void* in, void* out, int64_t M, int64_t H, int64_t W, int erode, void* stream);
+/* cv2.dilate followed by cv2.erode (:156-157) in one pass over byte images [M,H,W] (the dilated image never leaves LDS); same
+ * border rules as simseg_morph7 applied twice.  valid (optional, [M] ints): images with valid[m] < 0 are skipped and their
+ * output left untouched (candidate slots the reference never visits). */
+int simseg_close7(const void* in, void* out, const int* valid, int64_t M, int64_t H, int64_t W, void* stream);
 /* masks [B,ncand,Hm,Wm] bytes -> nearest resize to (H,W) (cv2.INTER_NEAREST :159) -> temp_pred[class] = mask * score (:160) ->
  * argmax over classes (:163; first maximum, class 0 when nothing is positive) -> pred [B,H,W] int32 (optional) and
  * hist [3,C] uint64 += {intersect, pred area, label area} over pixels whose label != ignore_index (utils/metrics.py:60-74).

@@ -152,6 +152,64 @@ __global__ __launch_bounds__(256) void morph7_kernel(const unsigned char* __rest
     }
 }
 
+// K19b: cv2.dilate followed by cv2.erode (7x7, one iteration each) in ONE pass: a 64x64 output tile needs the input with a
+// halo of 6; the dilated intermediate (halo 3) lives only in LDS, and positions of it outside the image are set to 255 so
+// the erosion ignores them exactly as cv2's border rule does.  `valid` (optional, one int per image) < 0 skips the image:
+// slots the reference never visits (most of the five candidates of an image) cost nothing.
+constexpr int CT = 64, CH = 6, CIN = CT + 2 * CH, CMID = CT + 2 * MR;
+__global__ __launch_bounds__(256) void close7_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, const int* __restrict__ valid,
+                                                     int H, int W) {
+    __shared__ unsigned char A[CIN][CIN + 4];
+    __shared__ unsigned char Bh[CIN][CMID + 2];
+    __shared__ unsigned char C[CMID][CMID + 2];
+    __shared__ unsigned char D[CMID][CT];
+    if (valid && valid[blockIdx.z] < 0) return;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+    const unsigned char* src = in + (long)blockIdx.z * H * W;
+    unsigned char* dst = out + (long)blockIdx.z * H * W;
+    for (int i = tid; i < CIN * CIN; i += 256) {
+        const int ty = i / CIN, tx = i % CIN;
+        const int y = y0 + ty - CH, x = x0 + tx - CH;
+        A[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(long)y * W + x] : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < CIN * CMID; i += 256) {            // horizontal max: Bh[y][x] covers input columns x .. x+6
+        const int ty = i / CMID, tx = i % CMID;
+        unsigned char m = A[ty][tx];
+#pragma unroll
+        for (int d = 1; d <= 2 * MR; ++d) { const unsigned char t = A[ty][tx + d]; m = t > m ? t : m; }
+        Bh[ty][tx] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < CMID * CMID; i += 256) {           // vertical max -> dilated value at (y0 - 3 + ty, x0 - 3 + tx)
+        const int ty = i / CMID, tx = i % CMID;
+        unsigned char m = Bh[ty][tx];
+#pragma unroll
+        for (int d = 1; d <= 2 * MR; ++d) { const unsigned char t = Bh[ty + d][tx]; m = t > m ? t : m; }
+        const int y = y0 - MR + ty, x = x0 - MR + tx;
+        C[ty][tx] = (y >= 0 && y < H && x >= 0 && x < W) ? m : 255;
+    }
+    __syncthreads();
+    for (int i = tid; i < CMID * CT; i += 256) {             // horizontal min
+        const int ty = i / CT, tx = i % CT;
+        unsigned char m = C[ty][tx];
+#pragma unroll
+        for (int d = 1; d <= 2 * MR; ++d) { const unsigned char t = C[ty][tx + d]; m = t < m ? t : m; }
+        D[ty][tx] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < CT * CT; i += 256) {               // vertical min -> output
+        const int ty = i / CT, tx = i % CT;
+        const int y = y0 + ty, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        unsigned char m = D[ty][tx];
+#pragma unroll
+        for (int d = 1; d <= 2 * MR; ++d) { const unsigned char t = D[ty + d][tx]; m = t < m ? t : m; }
+        dst[(long)y * W + x] = m;
+    }
+}
+
 // K20: masks [B, ncand, Hm, Wm] -> pred [B, H, W] (optional) + hist [3, C] += (intersect, pred, label) pixel counts.
 constexpr int HIST_MAXC = 1024;
 __global__ __launch_bounds__(256) void seg_predict_kernel(const unsigned char* __restrict__ masks, const int* __restrict__ cand_idx,
@@ -170,6 +228,39 @@ __global__ __launch_bounds__(256) void seg_predict_kernel(const unsigned char* _
     __syncthreads();
     const double fy = (double)Hm / (double)H, fx = (double)Wm / (double)W;      // cv2.resize INTER_NEAREST: src = floor(dst * scale)
     const long npix = (long)H * W;
+    if (Hm == H && Wm == W && (npix & 3) == 0 && !pred) {
+        // same-size maps (windowed evaluation), histograms only: four pixels per thread, one 32-bit load per candidate map
+        const unsigned int* lab4 = reinterpret_cast<const unsigned int*>(labels + (long)b * npix);
+        for (long i = (long)blockIdx.x * 256 + tid; i < (npix >> 2); i += (long)gridDim.x * 256) {
+            unsigned int mk[8];
+            for (int k = 0; k < ncand; ++k)
+                mk[k] = cidx[k] >= 0 ? reinterpret_cast<const unsigned int*>(masks + ((long)b * ncand + k) * npix)[i] : 0u;
+            const unsigned int lw = lab4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double best = 0.0;
+                int bi = 0;
+                for (int k = 0; k < ncand; ++k) {
+                    const int ci = cidx[k];
+                    if (ci < 0) continue;
+                    const double val = (double)((mk[k] >> (8 * e)) & 0xffu) * cval[k];
+                    if (val > best || (val == best && ci < bi)) { best = val; bi = ci; }
+                }
+                const int l = (int)((lw >> (8 * e)) & 0xffu);
+                if (l != ignore) {
+                    atomicAdd(&lh[C + bi], 1u);
+                    if (l < C) {
+                        atomicAdd(&lh[2 * C + l], 1u);
+                        if (l == bi) atomicAdd(&lh[l], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 3 * C; i += 256)
+            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + tid; i < npix; i += (long)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i % W);
         int sy = (int)floor(y * fy), sx = (int)floor(x * fx);
@@ -233,6 +324,16 @@ extern "C" int simseg_morph7(const void* in, void* out, int64_t M, int64_t H, in
     hipLaunchKernelGGL(morph7_kernel, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned char*>(in),
                        static_cast<unsigned char*>(out), (int)H, (int)W, erode);
     SS_LAUNCH_CHECK("morph7");
+    return 0;
+}
+
+extern "C" int simseg_close7(const void* in, void* out, const int* valid, int64_t M, int64_t H, int64_t W, void* stream) {
+    SS_CHECK(in && out && in != out, "close7: null or aliased pointers");
+    SS_CHECK(M > 0 && M < 65536 && H > 0 && W > 0, "close7: bad shape");
+    dim3 grid((unsigned)((W + CT - 1) / CT), (unsigned)((H + CT - 1) / CT), (unsigned)M);
+    hipLaunchKernelGGL(close7_kernel, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const unsigned char*>(in),
+                       static_cast<unsigned char*>(out), valid, (int)H, (int)W);
+    SS_LAUNCH_CHECK("close7");
     return 0;
 }
 

@@ -314,6 +314,19 @@ def morph7(img, erode):
     return out
 
 
+def close7(img, valid=None):
+    """cv2.dilate then cv2.erode (7x7, one iteration each) in one pass on uint8 [..., H, W]; `valid` (int32, one per image): images
+    with a negative entry are skipped and come back zero."""
+    require_gpu(img)
+    if img.dtype != torch.uint8:
+        raise TypeError("close7: uint8 images")
+    x = _c(img)
+    H, W = x.shape[-2:]
+    out = torch.zeros_like(x) if valid is not None else torch.empty_like(x)
+    call("simseg_close7", ptr(x), ptr(out), ptr(_c(valid)) if valid is not None else None, x.numel() // (H * W), H, W, stream())
+    return out
+
+
 def seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index=255, hist=None, want_pred=True):
     """masks [B,ncand,Hm,Wm] uint8, labels [B,H,W] uint8 -> (pred [B,H,W] int32 or None, hist [3,C] int64 accumulated:
     rows = intersect, pred area, label area)."""

@@ -27,7 +27,7 @@ def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand
         up = prob.view(B, K, num_patch, num_patch).repeat_interleave(16, 2).repeat_interleave(16, 3)
         masks = refine(up, cand_idx, cand_score).to(torch.uint8).contiguous()
     if closing:
-        masks = ops.morph7(ops.morph7(masks, erode=False), erode=True)        # cv2.dilate then cv2.erode (:156-157)
+        masks = ops.close7(masks, cand_idx.reshape(-1))                       # cv2.dilate then cv2.erode (:156-157), visited slots only
     pred, hist = ops.seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index, hist=hist, want_pred=want_pred)
     return {"pred": pred, "hist": hist, "cand_idx": cand_idx, "cand_score": cand_score, "threshold": thr, "masks": masks}
 

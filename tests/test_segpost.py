@@ -121,6 +121,22 @@ def test_morph7_vs_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 45, 61), (2, 130, 257), (1, 64, 64)])
+def test_close7_equals_dilate_then_erode(shape):
+    from simseg_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for img in ((torch.rand(shape, generator=g) < 0.1).to(torch.uint8) * 255, torch.randint(0, 256, shape, generator=g, dtype=torch.int64).to(torch.uint8)):
+        x = img.cuda()
+        two = ops.morph7(ops.morph7(x, False), True)
+        assert torch.equal(ops.close7(x), two)
+        valid = torch.tensor([5, -1, 2][:shape[0]], dtype=torch.int32).cuda()
+        part = ops.close7(x, valid)
+        for m in range(shape[0]):
+            assert torch.equal(part[m], two[m] if int(valid[m]) >= 0 else torch.zeros_like(two[m]))
+        assert np.array_equal(two[0].cpu().numpy(), SR.morph7(SR.morph7(img[0].numpy(), False), True))
+
+
+@pytest.mark.gpu
 def test_refine_hook_and_closing_on_irregular_masks():
     # a caller-supplied refinement (stands in for a CRF) produces masks that are NOT patch aligned: the morphology matters
     from simseg_amd import segpost
@@ -163,6 +179,8 @@ def test_fullsize_512_window_properties():
     valid = int((labels != 255).sum())
     assert int(a["hist"][1].sum()) == valid and int(a["hist"][2].sum()) == valid
     assert int(a["hist"][0].sum()) == int(((a["pred"] == labels.int()) & (labels != 255)).sum())
+    c = segpost.segment(sim, scores, labels, n, 10, want_pred=False)           # histogram-only fast path (4 pixels per thread)
+    assert c["pred"] is None and torch.equal(c["hist"], a["hist"])
     allowed = set([0] + [i for row in a["cand_idx"].tolist() for i in row if i >= 0])
     assert set(a["pred"].unique().tolist()) <= allowed
 
