@@ -133,18 +133,28 @@ def main():
         mean = torch.tensor(cfg.transforms.normalize.mean, device=ENV.device).view(1, 3, 1, 1)
         std = torch.tensor(cfg.transforms.normalize.std, device=ENV.device).view(1, 3, 1, 1)
         count, t0 = 0, time.perf_counter()
+        # consecutive batches alternate between two HIP streams (two batches in flight: one's attention / LayerNorm / post-processing
+        # fills the GEMM tails of the other); the histograms accumulate atomically, so no ordering between batches is needed
+        streams = [torch.cuda.Stream(device=ENV.device) for _ in range(2)]
+        cur = torch.cuda.current_stream()
         with torch.no_grad():
-            for image, label in batches(name):
+            for i, (image, label) in enumerate(batches(name)):
                 image, label = image.to(ENV.device), label.to(ENV.device)
-                feats = model.forward_image_feature(image)
-                pooled = model.forward_image_project(feats)
-                sim = patch_text_similarity(model.image_projection(feats), text)
-                refine = None
-                if args.crf:
-                    raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
-                    refine = host_crf_refine(raw)
-                segpost.segment(sim, ops.gemm(pooled, text), label, n, top_cls_num, hist=hist, want_pred=False, refine=refine)
+                st = streams[i % 2]
+                st.wait_stream(cur)
+                image.record_stream(st); label.record_stream(st)
+                with torch.cuda.stream(st):
+                    feats = model.forward_image_feature(image)
+                    pooled = model.forward_image_project(feats)
+                    sim = patch_text_similarity(model.image_projection(feats), text)
+                    refine = None
+                    if args.crf:
+                        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+                        refine = host_crf_refine(raw)
+                    segpost.segment(sim, ops.gemm(pooled, text), label, n, top_cls_num, hist=hist, want_pred=False, refine=refine)
                 count += image.shape[0]
+        for st in streams:
+            cur.wait_stream(st)
         torch.cuda.synchronize()
         iou, miou = segpost.iou_from_hist(hist)
         dt = time.perf_counter() - t0
