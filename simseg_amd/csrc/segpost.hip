@@ -247,11 +247,18 @@ __global__ __launch_bounds__(256) void seg_predict_kernel(const unsigned char* _
                     if (val > best || (val == best && ci < bi)) { best = val; bi = ci; }
                 }
                 const int l = (int)((lw >> (8 * e)) & 0xffu);
-                if (l != ignore) {
-                    atomicAdd(&lh[C + bi], 1u);
+                // label maps are spatially coherent: most waves see ONE (prediction, label) pair, which would be a 64-way
+                // conflict on three LDS counters.  Lanes agreeing with the first lane are counted by one lane.
+                const int key = (bi << 8) | l;
+                const int k0 = __builtin_amdgcn_readfirstlane(key);
+                const unsigned long long same = __ballot(key == k0);
+                const bool leader = (key == k0) && (__builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u)) == 0);
+                const unsigned cnt = (key == k0) ? (leader ? (unsigned)__popcll(same) : 0u) : 1u;
+                if (cnt && l != ignore) {
+                    atomicAdd(&lh[C + bi], cnt);
                     if (l < C) {
-                        atomicAdd(&lh[2 * C + l], 1u);
-                        if (l == bi) atomicAdd(&lh[l], 1u);
+                        atomicAdd(&lh[2 * C + l], cnt);
+                        if (l == bi) atomicAdd(&lh[l], cnt);
                     }
                 }
             }

@@ -181,6 +181,13 @@ def test_fullsize_512_window_properties():
     assert int(a["hist"][0].sum()) == int(((a["pred"] == labels.int()) & (labels != 255)).sum())
     c = segpost.segment(sim, scores, labels, n, 10, want_pred=False)           # histogram-only fast path (4 pixels per thread)
     assert c["pred"] is None and torch.equal(c["hist"], a["hist"])
+    # spatially coherent labels (what real masks look like): whole waves agree on (prediction, label) and are counted by one lane
+    blocks = torch.randint(0, C, (B, 8, 8), generator=torch.Generator().manual_seed(8), dtype=torch.int64).to(torch.uint8)
+    coh = blocks.repeat_interleave(64, 1).repeat_interleave(64, 2).contiguous().cuda()
+    coh[:, :40, :] = 255
+    d1 = segpost.segment(sim, scores, coh, n, 10, want_pred=True)
+    d2 = segpost.segment(sim, scores, coh, n, 10, want_pred=False)
+    assert torch.equal(d1["hist"], d2["hist"]) and int(d2["hist"][2].sum()) == int((coh != 255).sum())
     allowed = set([0] + [i for row in a["cand_idx"].tolist() for i in row if i >= 0])
     assert set(a["pred"].unique().tolist()) <= allowed
 
