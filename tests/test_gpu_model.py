@@ -350,3 +350,42 @@ def test_graphed_forward_matches_eager(golden, monkeypatch):
             got = gc(im)
             torch.cuda.synchronize()
             assert _maxerr(got[0], want[0]) < 1e-6 and torch.equal(got[1], want[1]) and _maxerr(got[2], want[2]) < 1e-6, mode
+
+
+def test_training_trajectory_follows_oracle(golden, monkeypatch):
+    """40 AdamW steps on a fixed batch (tiny towers, eval mode = no dropout): the bf16 HIP path's loss curve stays on the curve the
+    fp32 CPU oracle produces with torch.optim.AdamW from the same initial weights, and both memorise the batch."""
+    from oracle import simseg_ref as R
+    from simseg_amd.optim import AdamW
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    g = golden("clip_train_ws1")
+    gw = golden("clip_glue")
+    ref = R.RefCLIP("vit_test_patch16", "bert-test", img_size=96)
+    ref.load_state_dict({k[3:]: tt(gw[k]) for k in gw.files if k.startswith("sd.")}, strict=False)
+    ref.eval()
+    m = _build(golden)
+    m.eval()
+    image, ids, mask = tt(g["r0.image"]), tt(g["r0.input_ids"]), tt(g["r0.attention_mask"])
+    batch = {"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()}
+    hp = dict(lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    opt = AdamW(m.parameters(), **hp)
+    opt_ref = torch.optim.AdamW(ref.parameters(), **hp)
+    ours, want = [], []
+    torch.set_num_threads(8)
+    for _ in range(40):
+        opt.zero_grad(set_to_none=True)
+        loss = m(batch)[0]["nce_loss"]
+        loss.backward()
+        opt.step()
+        ours.append(float(loss.detach()))
+        opt_ref.zero_grad(set_to_none=True)
+        lr_, _, _ = ref.forward_loss_local(image, ids, mask)
+        lr_.backward()
+        opt_ref.step()
+        want.append(float(lr_.detach()))
+    print("ours", [round(x, 3) for x in ours[::5]], "oracle", [round(x, 3) for x in want[::5]])
+    assert want[-1] < 0.5 * want[0], want                      # the oracle memorises the batch ...
+    assert ours[-1] < 0.5 * ours[0], ours                      # ... and so does the HIP path
+    assert abs(ours[0] - want[0]) < 2e-2 * want[0]
+    for a, b in zip(ours[:10], want[:10]):                     # early steps: same curve (later ones diverge chaotically in any precision)
+        assert abs(a - b) < 0.1 * max(abs(b), 0.1), (ours[:10], want[:10])

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""End-to-end training sanity on one GPU: ViT-B/16 + BERT-base, one fixed synthetic batch, AdamW.  The loss must fall
+towards 0 (the batch is memorised) and stay finite with bf16 compute, dropout and two-stream towers on.  From a random init and
+without warm-up the config's 1e-4 collapses the embeddings (loss pinned at ln B) - the reference warms up over 2 epochs - so the
+default here is 2e-5: measured 5.22 -> 2.70 in 120 steps at 128 pairs (i2t accuracy 0.8 % -> 33 %).  tests/test_gpu_model.py
+::test_training_trajectory_follows_oracle pins the step-by-step curve against the CPU oracle on the tiny towers."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+    dev = torch.device("cuda", 0)
+    from simseg.core import init_device
+    from simseg.models import PIPELINE
+    from simseg_amd.optim import AdamW
+    cfg, build = bench.build_model("vit_base_patch16_224_in21k", 768, 224)
+    init_device(cfg)
+    torch.manual_seed(1234)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
+    if os.environ.get("SANITY_FREEZE_TEMP") == "1":
+        model.loss.temperature.requires_grad_(False)
+    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=float(os.environ.get("SANITY_LR", "2e-5")), betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    batch = bench.synthetic_batch(pairs, 224, 77, 30522, 1000, dev)
+    if os.environ.get("SANITY_IMAGES", "blocks") == "blocks":
+        # i.i.d. noise images are nearly indistinguishable after patch embedding + LayerNorm at initialisation (the loss then sits at
+        # ln(B) for a long time); give every image a strong low-frequency signature instead: a random 14x14 pattern, one value per patch
+        g = torch.Generator().manual_seed(5)
+        low = torch.randn(pairs, 3, 14, 14, generator=g)
+        batch["image"] = low.repeat_interleave(16, 2).repeat_interleave(16, 3).to(dev).contiguous()
+    for i in range(steps):
+        opt.zero_grad(set_to_none=True)
+        out, i2t, t2i = model(batch)
+        loss = out["nce_loss"]
+        loss.backward()
+        opt.step()
+        if i % 10 == 0 or i == steps - 1:
+            print(f"step {i:4d}  loss {float(loss.detach()):8.4f}  i2t acc {float(i2t):.3f}  t2i acc {float(t2i):.3f}", flush=True)
+            assert torch.isfinite(loss.detach()), "non-finite loss"
