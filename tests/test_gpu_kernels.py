@@ -226,6 +226,52 @@ def test_bert_embed(ops):
     _close(dword, refw, 1e-5, "bert embed bwd")
 
 
+def test_gemm_randomised_shapes_and_epilogues(ops):
+    """40 seeded random problems through whatever kernel the dispatcher picks (128x128 register-staged, 256x256 direct-to-LDS,
+    split-K): ragged M / N, every operand orientation, bf16 and fp32, with bias / GELU / fp32 residual / column sums."""
+    import random
+    rng = random.Random(1234)
+    for case in range(40):
+        bf = rng.random() < 0.7
+        ta = bf and rng.random() < 0.25
+        tb = bf and (ta or rng.random() < 0.5)  # transposed operands are a bf16 (training) feature; (ta, !tb) is not on the path
+        M = rng.choice([1, 7, 64, 200, 257, 777, 1025, 2304, 4100])
+        N = rng.choice([8, 24, 128, 264, 768, 1000, 1536]) if bf else rng.choice([3, 21, 128, 171, 512])
+        K = rng.choice([64, 128, 320, 768, 1536]) if bf else rng.choice([1, 40, 96, 512])
+        if bf and (ta or tb):
+            N = (N + 7) // 8 * 8
+        if ta:
+            M = (M + 7) // 8 * 8
+        dt_ = torch.bfloat16 if bf else torch.float32
+        a = _rand(*((K, M) if ta else (M, K)), seed=case, dtype=dt_)
+        b = _rand(*((K, N) if tb else (N, K)), seed=case + 100, dtype=dt_)
+        A = a.float().t() if ta else a.float()
+        Bm = b.float() if tb else b.float().t()
+        ref = A @ Bm
+        kw, what = {}, f"case {case}: M={M} N={N} K={K} ta={ta} tb={tb} {'bf16' if bf else 'f32'}"
+        mode = rng.choice(["plain", "bias", "gelu", "residual", "colsum"])
+        if mode in ("bias", "gelu", "residual"):
+            bias = _rand(N, seed=case + 200)
+            kw["bias"] = bias
+            ref = ref + bias.float().cpu().cuda()
+        if mode == "gelu":
+            kw["act"] = 1
+            ref = F.gelu(ref)
+        if mode == "residual":
+            res = _rand(M, N, seed=case + 300)
+            kw.update(residual=res, out_dtype=torch.float32)
+            ref = ref + res
+        cs = None
+        if mode == "colsum":
+            cs = torch.zeros(N, device="cuda")
+            kw["colsum"] = cs
+        out = ops.gemm(a, b, trans_a=ta, trans_b=tb, **kw)
+        tol = 2e-2 if bf and out.dtype == torch.bfloat16 else (2e-5 if not bf else 1e-4)
+        _close(out, ref, tol, what + " " + mode)
+        if cs is not None:
+            _close(cs, ref.sum(0), 1e-4, what + " column sums (of the fp32 values, before the output is rounded)")
+
+
 def test_topk_pool_sliced_equals_single_pass(ops):
     """Small batches scan token slices in parallel and merge; the result - selected indices included, with the many ties of
     bf16 data - is the single-pass kernel's."""
