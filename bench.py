@@ -319,17 +319,26 @@ def main():
     torch.manual_seed(1234)
     model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
     net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
+    sync = None
+    dp = os.environ.get("SIMSEG_BENCH_DP", "ddp")      # "ddp": torch DDP (bucketed all-reduce overlapped with backward, towers on one
+    if world > 1:                                       # stream); "flat": simseg_amd.parallel.GradSync (one all-reduce, two-stream towers)
+        if dp == "flat":
+            from simseg_amd.parallel import GradSync
+            sync = GradSync(model.parameters())
+            os.environ.setdefault("SIMSEG_AMD_TWO_STREAMS", "1")
+        else:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
     opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
     B, L = args.pairs_per_gpu, args.seq_len
     batch = synthetic_batch(B, args.img, L, 30522, 1000 + rank, dev)
     log("model and batch on device")
 
     def step():
-        opt.zero_grad(set_to_none=(world == 1))     # under DDP the grads are views into the all-reduce buckets
+        opt.zero_grad(set_to_none=(world == 1 or sync is not None))     # under DDP the grads are views into the all-reduce buckets
         loss_dict, _, _ = net(batch)
         loss_dict["nce_loss"].backward()
+        if sync is not None:
+            sync()
         opt.step()
         return loss_dict["nce_loss"]
 
@@ -358,6 +367,8 @@ def main():
     # that kernel's own speed); the instrumented step runs them on ONE stream so that each launch is timed alone.
     env_ts = os.environ.get("SIMSEG_AMD_TWO_STREAMS")
     two_streams = (env_ts != "0") if env_ts is not None else world == 1      # the default of simseg/models/pipelines/clip.py
+    if sync is not None:
+        two_streams = os.environ.get("SIMSEG_AMD_TWO_STREAMS") != "0"
     os.environ["SIMSEG_AMD_TWO_STREAMS"] = "0"
     ops.PROFILE = []
     step()
@@ -416,6 +427,7 @@ def main():
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
+                       "gradient_sync": ("none" if world == 1 else ("flat all-reduce (simseg_amd.parallel.GradSync)" if sync is not None else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
