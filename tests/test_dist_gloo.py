@@ -61,6 +61,18 @@ def _worker(rank, world, port, q):
     objs = [{"rank": rank}, "x" * (rank + 1)]
     broadcast_object_list(objs, src=0)
     res["bobj"] = objs
+    # hook-free gradient synchronisation (simseg_amd/parallel.py): flat all-reduce, grads re-pointed at views of the flat buffer
+    from simseg_amd.parallel import GradSync
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    lin[1].bias.requires_grad_(False)
+    sync = GradSync(lin.parameters())
+    x = torch.full((5, 4), float(rank + 1))
+    lin(x).square().sum().backward()
+    local = [p.grad.clone() for p in lin.parameters() if p.requires_grad]
+    sync()
+    res["gsync"] = ([g_.tolist() for g_ in local], [p.grad.tolist() for p in lin.parameters() if p.requires_grad],
+                    all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views)))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,3 +102,8 @@ def test_gather_layer_matches_reference_two_ranks(world):
         assert o["awg"] == ([1.0, 2.0], [float(r + 1)] * 3)          # gradient of this rank's slot only
         assert o["blist"] == [1, 8]
         assert o["bobj"] == [{"rank": 0}, "x"]
+        assert o["gsync"][2]
+    for k in range(len(out[0]["gsync"][0])):                     # every rank ends with the mean of the two ranks' local gradients
+        mean = (np.array(out[0]["gsync"][0][k]) + np.array(out[1]["gsync"][0][k])) / 2
+        for r in range(world):
+            np.testing.assert_allclose(np.array(out[r]["gsync"][1][k]), mean, rtol=1e-6, atol=1e-7)
