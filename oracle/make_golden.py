@@ -19,9 +19,10 @@ import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLD = os.path.join(REPO, "tests", "golden")
+GOLD = os.environ.get("SIMSEG_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")     # the regeneration check writes elsewhere
 REF = "/root/reference"
-sys.path.insert(0, REPO)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 
 
 def _import_reference():
@@ -31,8 +32,13 @@ def _import_reference():
             m = types.ModuleType(name)
             m.__spec__ = importlib.machinery.ModuleSpec(name, None)
             sys.modules[name] = m
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
+    # the reference's `simseg` package must shadow this repo's host-side mirror of the same name.  Spawned workers inherit the
+    # parent's sys.path and then re-execute this module (which puts REPO in front again), so REF is always MOVED to the front.
+    while REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, REF)
+    if "simseg" in sys.modules and not os.path.abspath(sys.modules["simseg"].__file__).startswith(REF):
+        raise RuntimeError("this repo's `simseg` mirror is already imported; fixtures must come from the reference package")
     os.environ.setdefault("HOSTNAME", "localhost")
     import simseg  # noqa: F401
     import simseg.utils  # noqa: F401
