@@ -138,12 +138,13 @@ int simseg_recall_counts(const int32_t* has_match, const int32_t* rank, int64_t 
 int simseg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
-/* Same update for every parameter tensor in ONE launch.  table[t] = {p, g, m, v, p16} (5 device pointers per tensor; p16 =
- * bf16 compute copy to refresh, or 0), sizes[t] elements, weight_decay[t]; chunk c covers [chunk_off[c], chunk_off[c]+chunk)
- * of tensor chunk_tid[c]. */
+/* Same update for every parameter tensor in ONE launch.  table[t] = six 8-byte words {p, g, m, v, p16, (float lr, float wd)}: five
+ * device pointers (p16 = bf16 compute copy to refresh, or 0) and the tensor's own learning rate / weight decay packed as two floats
+ * (the reference's ClipOptimizerHook makes one param group per parameter, tasks/clip/hooks/optimizer.py:18-36); sizes[t] elements;
+ * chunk c covers [chunk_off[c], chunk_off[c]+chunk) of tensor chunk_tid[c]. */
 int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
-                            int64_t n_chunks, int chunk, float lr, float beta1, float beta2, float eps, const float* weight_decay,
-                            int64_t step, float grad_scale, void* stream);
+                            int64_t n_chunks, int chunk, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                            void* stream);
 
 int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);

@@ -184,26 +184,29 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-// Multi-tensor form: one launch for every parameter tensor.  table[t] = {p, g, m, v, p16} device pointers, sizes[t] elements;
-// chunk c of the launch covers elements [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tid[c].  p16 (may be null) is the
-// bf16 compute copy the next forward's GEMMs read: refreshed here, so no per-step cast kernels.
-struct AdamTensors { float* p; const float* g; float* m; float* v; bf16_t* p16; };
+// Multi-tensor form: one launch for every parameter tensor.  table[t] = {p, g, m, v, p16, lr, weight_decay}: five device pointers and
+// the tensor's own learning rate / weight decay (the reference builds one param group per parameter, tasks/clip/hooks/optimizer.py:18-36);
+// sizes[t] elements; chunk c of the launch covers elements [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tid[c].  p16 (may be
+// null) is the bf16 compute copy the next forward's GEMMs read: refreshed here, so no per-step cast kernels.
+struct AdamTensors { float* p; const float* g; float* m; float* v; bf16_t* p16; float lr; float wd; };
+static_assert(sizeof(AdamTensors) == 48, "table rows are six 8-byte words");
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __restrict__ table, const long* __restrict__ sizes,
                                                           const int* __restrict__ chunk_tid, const long* __restrict__ chunk_off,
-                                                          int chunk, float lr, float b1, float b2, float eps, const float* __restrict__ wd,
-                                                          float bc1, float bc2_sqrt, float grad_scale) {
+                                                          int chunk, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                          float grad_scale) {
     const int c = blockIdx.x;
     const int t = chunk_tid[c];
     const AdamTensors T = table[t];
     const long lo = chunk_off[c];
     const long hi = min(sizes[t], lo + chunk);
-    const float decay = 1.0f - lr * wd[t];
+    const float decay = 1.0f - T.lr * T.wd;
+    const float step_size = T.lr / bc1;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
         const float gi = T.g[i] * grad_scale;
         float pi = T.p[i] * decay;
         const float mi = b1 * T.m[i] + (1.0f - b1) * gi;
         const float vi = b2 * T.v[i] + (1.0f - b2) * gi * gi;
-        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
         T.p[i] = pi; T.m[i] = mi; T.v[i] = vi;
         if (T.p16) T.p16[i] = (bf16_t)pi;
     }
@@ -271,15 +274,15 @@ extern "C" int simseg_recall_counts(const int32_t* has_match, const int32_t* ran
 }
 
 extern "C" int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
-                                       int64_t n_chunks, int chunk, float lr, float beta1, float beta2, float eps,
-                                       const float* weight_decay, int64_t step, float grad_scale, void* stream) {
-    SS_CHECK(table && sizes && chunk_tid && chunk_off && weight_decay, "adamw_multi_step: null pointer");
+                                       int64_t n_chunks, int chunk, float beta1, float beta2, float eps, int64_t step,
+                                       float grad_scale, void* stream) {
+    SS_CHECK(table && sizes && chunk_tid && chunk_off, "adamw_multi_step: null pointer");
     SS_CHECK(step >= 1 && chunk > 0, "adamw_multi_step: bad step/chunk");
     if (n_chunks <= 0) return 0;
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, STREAM, (const AdamTensors*)table, (const long*)sizes,
-                       (const int*)chunk_tid, (const long*)chunk_off, chunk, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       (const int*)chunk_tid, (const long*)chunk_off, chunk, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
     SS_LAUNCH_CHECK("adamw_multi_step");
     return 0;
 }

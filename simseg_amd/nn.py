@@ -36,9 +36,18 @@ def compute_dtype():
 _seed_state = [0x5EED]
 
 
+def _rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(os.environ.get("RANK", "0") or 0)
+
+
 def next_dropout_seed():
+    """Seed of the next forward's dropout masks: a per-process LCG stream, offset by the data-parallel rank so that the ranks of
+    a job draw different masks (torch seeds every rank's generator separately, simseg/utils/initial.py)."""
     _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) % (1 << 62)
-    return _seed_state[0]
+    return (_seed_state[0] + _rank() * 0x9E3779B97F4A7C15) % (1 << 62)
 
 
 def manual_dropout_seed(seed):

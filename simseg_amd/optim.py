@@ -1,17 +1,24 @@
-"""AdamW on the fused HIP kernels.  Same update rule and hyper-parameters as the reference's torch.optim.AdamW
-(configs/clip/simseg.vit-b.yaml:31-36); state (m, v) is fp32.  All parameter tensors of a param group are updated by ONE
-kernel launch (simseg_adamw_multi_step): a device table of {p, g, m, v, p16} pointers is refreshed from a pinned host buffer each
-step (gradient tensors are re-allocated by autograd), without a host-device synchronisation.  p16 is the bf16 compute copy of
-the parameter, written by the same kernel and handed to the towers (towers.register_w16), so a training step launches no
-weight-cast kernels."""
+"""AdamW on the fused HIP kernel.  Same update rule and hyper-parameters as the reference's torch.optim.AdamW
+(configs/clip/simseg.vit-b.yaml:31-36); state (m, v) is fp32.
+
+ONE kernel launch updates every parameter tensor of every param group (the reference's ClipOptimizerHook builds one group per
+parameter, tasks/clip/hooks/optimizer.py:18-36, so "one launch per group" would be ~400 launches): a device table of
+{p, g, m, v, p16, lr, weight_decay} rows is refreshed from pinned host memory each step (gradient tensors are re-allocated by
+autograd, learning rates follow the schedule) without a host-device synchronisation.  The pinned staging buffers form a ring, each
+guarded by an event recorded after its upload, so the host never rewrites a buffer whose asynchronous copy has not executed yet.
+p16 is the bf16 compute copy of the parameter, written by the same kernel and handed to the towers (towers.register_w16), so a
+training step launches no weight-cast kernels.
+
+Checkpoints use torch.optim.AdamW's state layout ({step, exp_avg, exp_avg_sq} per parameter), so the reference's optimizer
+checkpoints (core/hooks/checkpoint.py:14-45) load here and ours load there; the bias-correction step counter travels with them."""
 import numpy as np
 import torch
 
-from . import ops
 from .lib import call, ptr, stream
 from .towers import register_w16
 
 CHUNK = 1 << 16
+RING = 4
 
 
 class AdamW(torch.optim.Optimizer):
@@ -20,63 +27,108 @@ class AdamW(torch.optim.Optimizer):
         self._step = 0
         self._plans = {}
 
-    def _plan(self, gi, params):
-        """Static part of a group's launch: state buffers, sizes, chunk map (rebuilt when the set of tensors changes)."""
-        key = tuple(id(p) for p in params)
-        plan = self._plans.get(gi)
-        if plan is not None and plan["key"] == key:
+    # ---- launch plan: everything about a set of tensors that does not change from step to step ------------------------------
+    def _plan(self, key, params):
+        ids = tuple(id(p) for p in params)
+        plan = self._plans.get(key)
+        if plan is not None and plan["ids"] == ids:
             return plan
         dev = params[0].device
         total = sum(p.numel() for p in params)
         m = torch.zeros(total, device=dev, dtype=torch.float32)
         v = torch.zeros(total, device=dev, dtype=torch.float32)
         p16 = torch.empty(total, device=dev, dtype=torch.bfloat16)
-        old = self._plans.get(gi)
-        offs, o = [], 0
+        o = 0
         for p in params:
-            offs.append(o)
             st = self.state[p]
-            if "m" in st:                     # keep moments across a re-plan
-                m[o:o + p.numel()].copy_(st["m"].reshape(-1)); v[o:o + p.numel()].copy_(st["v"].reshape(-1))
-            st["m"], st["v"] = m[o:o + p.numel()].view_as(p), v[o:o + p.numel()].view_as(p)
-            st["p16"] = p16[o:o + p.numel()].view_as(p)
-            o += p.numel()
+            n = p.numel()
+            if "m" in st:                     # keep moments across a re-plan / a loaded checkpoint
+                m[o:o + n].copy_(st["m"].reshape(-1)); v[o:o + n].copy_(st["v"].reshape(-1))
+            st["m"], st["v"], st["p16"] = m[o:o + n].view_as(p), v[o:o + n].view_as(p), p16[o:o + n].view_as(p)
+            o += n
         tid, coff = [], []
         for t, p in enumerate(params):
             for c in range(0, p.numel(), CHUNK):
                 tid.append(t); coff.append(c)
-        plan = dict(key=key, m=m, v=v, p16=p16,
+        static = np.zeros((len(params), 6), dtype=np.int64)
+        for t, p in enumerate(params):
+            st = self.state[p]
+            static[t, 0], static[t, 2], static[t, 3], static[t, 4] = p.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), st["p16"].data_ptr()
+        plan = dict(ids=ids, m=m, v=v, p16=p16, static=static,
                     sizes=torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev),
                     tid=torch.tensor(tid, dtype=torch.int32, device=dev), coff=torch.tensor(coff, dtype=torch.int64, device=dev),
-                    host=torch.empty(len(params), 5, dtype=torch.int64).pin_memory(),
-                    table=torch.empty(len(params), 5, dtype=torch.int64, device=dev), n_chunks=len(tid))
-        self._plans[gi] = plan
+                    ring=[torch.empty(len(params), 6, dtype=torch.int64).pin_memory() for _ in range(RING)],
+                    events=[None] * RING, slot=0,
+                    table=torch.empty(len(params), 6, dtype=torch.int64, device=dev), n_chunks=len(tid))
+        self._plans[key] = plan
         return plan
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         self._step += 1
-        for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
-                continue
+        buckets = {}
+        for group in self.param_groups:
+            key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
+            for p in group["params"]:
+                if p.grad is not None:
+                    buckets.setdefault(key, []).append((p, float(group["lr"]), float(group["weight_decay"])))
+        for key, items in buckets.items():
+            params = [it[0] for it in items]
             if any(not p.is_contiguous() or p.dtype != torch.float32 for p in params):
                 raise TypeError("simseg_amd AdamW expects contiguous fp32 master parameters")
-            plan = self._plan(gi, params)
+            plan = self._plan(key, params)
+            if any(p.data_ptr() != a for p, a in zip(params, plan["static"][:, 0])):       # storage swapped (.to(), load with assign)
+                self._plans.pop(key)
+                plan = self._plan(key, params)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
-            host = plan["host"].numpy()
-            for t, (p, g) in enumerate(zip(params, grads)):
-                st = self.state[p]
-                host[t, 0], host[t, 1], host[t, 2], host[t, 3] = p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
-                host[t, 4] = st["p16"].data_ptr()
-            plan["table"].copy_(plan["host"], non_blocking=True)
-            wd = plan.get("wd")
-            if wd is None or plan.get("wd_val") != group["weight_decay"]:
-                wd = plan["wd"] = torch.full((len(params),), float(group["weight_decay"]), device=params[0].device)
-                plan["wd_val"] = group["weight_decay"]
+            slot = plan["slot"]
+            plan["slot"] = (slot + 1) % RING
+            if plan["events"][slot] is not None:
+                plan["events"][slot].synchronize()          # the upload that last used this pinned buffer has executed (RING steps ago)
+            host = plan["ring"][slot].numpy()
+            host[:] = plan["static"]
+            host[:, 1] = [g.data_ptr() for g in grads]
+            hyper = np.empty((len(params), 2), dtype=np.float32)
+            hyper[:, 0] = [it[1] for it in items]
+            hyper[:, 1] = [it[2] for it in items]
+            host[:, 5] = hyper.view(np.int64)[:, 0]
+            plan["table"].copy_(plan["ring"][slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            plan["events"][slot] = ev
             call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
-                 CHUNK, float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), ptr(wd),
-                 self._step, float(grad_scale), stream())
+                 CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
             plan["keepalive"] = grads        # the kernel reads them asynchronously
             for p in params:                 # same stream as the next forward: the copies are current when it runs
                 register_w16(p, self.state[p]["p16"])
+
+    # ---- checkpoints in torch.optim.AdamW's layout ---------------------------------------------------------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        out = {}
+        for idx, st in sd["state"].items():
+            if "m" in st:
+                out[idx] = {"step": torch.tensor(float(self._step)), "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
+        sd["state"] = out
+        for g in sd["param_groups"]:            # keys torch.optim.AdamW.load_state_dict expects to find
+            g.setdefault("amsgrad", False)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        steps, conv = [], {}
+        for idx, st in sd["state"].items():
+            if "exp_avg" in st:
+                conv[idx] = {"m": st["exp_avg"], "v": st["exp_avg_sq"]}
+                steps.append(int(float(st["step"])))
+            elif "m" in st:                     # round-1 checkpoints of this package
+                conv[idx] = {"m": st["m"], "v": st["v"]}
+        sd["state"] = conv
+        if "_step" in state_dict:
+            steps.append(int(state_dict["_step"]))
+        super().load_state_dict(sd)
+        self._plans.clear()                     # moments are re-packed (and the bf16 copies rewritten) by the next step
+        for st in self.state.values():
+            st["m"], st["v"] = st["m"].float().contiguous(), st["v"].float().contiguous()
+            st.pop("p16", None)
+        self._step = max(steps) if steps else 0

@@ -81,18 +81,27 @@ def _bgrad(dy16, out=None):
     return db
 
 
-# bf16 copy + column sums of a gradient tensor handed from one block's backward to the next (saves a cast pass and a
-# column-sum pass per block).  Keyed by the fp32 tensor's storage address; consumed (popped) by the receiver.
-_SHADOW = {}
+# bf16 copy + column sums of a gradient tensor handed from one block's backward to the next (saves a cast pass and a column-sum
+# pass per block).  The pair rides on the fp32 gradient tensor itself (autograd hands the same tensor object to the consumer node;
+# its Python attributes travel with it) together with the tensor's version counter: if autograd accumulated another gradient into
+# the buffer in place (a block output with two consumers), or anything else wrote to it, the version has moved and the shadow is
+# ignored -- the consumer then casts / sums the tensor it was actually given.  Nothing is keyed by address, nothing is global.
+SHADOW_HITS = [0]     # consumed shadows (tests assert that the fast path is the one that runs)
 
 
 def _put_shadow(t32, t16, colsum):
-    _SHADOW.clear()
-    _SHADOW[(t32.data_ptr(), tuple(t32.shape))] = (t16, colsum)
+    t32._simseg_shadow = (t16, colsum, t32._version)
 
 
 def _take_shadow(t32):
-    return _SHADOW.pop((t32.data_ptr(), tuple(t32.shape)), None)
+    sh = getattr(t32, "_simseg_shadow", None)
+    if sh is None:
+        return None
+    del t32._simseg_shadow
+    if sh[2] != t32._version or sh[0].shape != t32.shape:
+        return None
+    SHADOW_HITS[0] += 1
+    return sh
 
 
 def _need_bf16(adt, what):
@@ -249,7 +258,6 @@ class ViTBlockFn(Function):
 
 def vit_forward(m, image, adt):
     """m: module tree with timm parameter names (see simseg_amd/nn.py ViT). Returns all tokens after the final LN."""
-    _SHADOW.clear()
     x = ViTEmbedFn.apply(image, m.patch_embed.proj.weight, m.patch_embed.proj.bias, m.cls_token, m.pos_embed, adt)
     for blk in m.blocks:
         x = ViTBlockFn.apply(x, m.num_heads, adt, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,

@@ -103,3 +103,89 @@ def test_ddp_wrapper_single_process_matches_plain(monkeypatch):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- full-size towers, both directions (ViT-B/16 + BERT-base dimensions: D=768, H=12, T=197 / L=77) ----------------------------------
+def _build_vitb(img_size, extra=()):
+    from conftest import REPO
+    from simseg.core.config import update_cfg
+    from simseg.models import PIPELINE
+    from simseg.tasks.clip.config import task_cfg_init_fn, update_clip_config
+    from simseg.utils import build_from_cfg
+    argv = [f"transforms.input_size={img_size}", "model.image_encoder.pretrained=False", "model.text_encoder.pretrained=False"]
+    cfg = update_cfg(task_cfg_init_fn, os.path.join(REPO, "configs/clip/simseg.vit-b.yaml"), argv + list(extra), update_clip_config)
+    return build_from_cfg(cfg.model.name, cfg, PIPELINE)
+
+
+def _cos(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
+    """BASELINE config 3's towers at full width and depth (ViT-B/16 @224: T=197, BERT-base L=77, ragged masks), B=6: bf16 forward +
+    InfoNCE + backward on the HIP path against the fp32 CPU oracle on the same weights.  This is the dispatch region of the 256x256
+    GEMM kernel's smaller sibling, the one-round split-K weight gradients, the 4-wave attention blocks and every fused epilogue.
+    Bar: loss within 1e-2 relative; EVERY parameter gradient with cosine >= 0.999 and norm within 3 % of the oracle's."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    from oracle import simseg_ref as R
+    B, L = 6, 77
+    ref = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=224), seed=12).eval()
+    m = _build_vitb(224)
+    missing, unexpected = m.load_state_dict(ref.state_dict(), strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing)
+    m = m.cuda().eval()                                      # eval: no dropout, so gradients are comparable
+    image = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(21))
+    ids, mask = R.synthetic_text(B, L, 30522, seed=22, min_len=8)
+    torch.set_num_threads(os.cpu_count() or 8)
+    want, _, _ = ref.forward_loss_local(image, ids, mask)
+    want.backward()
+    loss = m({"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})[0]["nce_loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want.item()) < 1e-2 * abs(want.item()), (loss.item(), want.item())
+    refp = dict(ref.named_parameters())
+    worst_c, worst_r, bad = 1.0, 0.0, []
+    for n, p in m.named_parameters():
+        gr = refp[n].grad
+        assert p.grad is not None and gr is not None, n
+        assert torch.isfinite(p.grad).all(), n
+        if float(gr.norm()) < 1e-6:
+            # BERT's key bias: softmax is invariant to a per-query shift of the scores, so this gradient is zero in exact arithmetic
+            # (the oracle holds ~1e-9 of fp32 noise).  Ours must be noise too: small against the query bias gradient next to it.
+            assert n.endswith("attention.self.key.bias"), (n, float(gr.norm()))
+            qn = float(refp[n.replace(".key.", ".query.")].grad.norm())
+            assert float(p.grad.float().norm()) < 0.02 * qn, (n, float(p.grad.float().norm()), qn)
+            continue
+        c = _cos(p.grad, gr)
+        r = float(p.grad.double().norm().cpu() / gr.double().norm())
+        worst_c, worst_r = min(worst_c, c), max(worst_r, abs(r - 1))
+        if not (c >= 0.999 and abs(r - 1) <= 0.03):
+            bad.append((n, round(c, 5), round(r, 4)))
+    print(f"ViT-B/BERT-base bf16 gradients vs fp32 oracle: worst cosine {worst_c:.5f}, worst |norm ratio - 1| {worst_r:.4f}")
+    assert not bad, bad
+
+
+def test_vitb_512_window_forward_vs_oracle(monkeypatch):
+    """Config 4's tower: ViT-B/16 on a 512x512 window (T = 1025, the 256x256-tile GEMM region for B*T >= 256 rows, 17 key tiles):
+    exact-fp32 kernels vs the CPU oracle <= 1e-3, and the bf16 path within bf16 noise of it."""
+    from oracle import simseg_ref as R
+    from simseg_amd.nn import ViT
+    ref = R.init_weights_(R.RefViT("vit_base_patch16_224_in21k", 512), seed=14).eval()
+    m = ViT("vit_base_patch16_224_in21k", 512)
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m = m.cuda().eval()
+    x = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(3))
+    torch.set_num_threads(os.cpu_count() or 8)
+    with torch.no_grad():
+        want = ref(x)
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+        got = m(x.cuda())
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+        got16 = m(x.cuda())
+    assert got.shape == (2, 1025, 768)
+    err = _maxerr(got, want)
+    assert err < 1e-3, err
+    rel16 = float((got16.float().cpu() - want).norm() / want.norm())
+    assert rel16 < 2e-2, rel16
+    print(f"ViT-B@512 fp32 max err {err:.2e}; bf16 relative L2 error {rel16:.2e}")

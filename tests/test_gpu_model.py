@@ -125,6 +125,8 @@ def test_train_step_ws1_vs_reference_golden(golden, monkeypatch):
     loss.backward()
     assert abs(loss.item() - float(g["r0.loss"])) < 2e-2 * abs(float(g["r0.loss"]))
     assert abs(a1.item() - float(g["r0.i2t_acc"])) < 1e-6 and abs(a2.item() - float(g["r0.t2i_acc"])) < 1e-6
+    from simseg_amd import towers
+    assert towers.SHADOW_HITS[0] > 0          # block-to-block bf16 gradient hand-off: the fast path is the one that ran
     params = dict(m.named_parameters())
     for k in g.files:
         if not k.startswith("r0.grad."):
@@ -256,8 +258,21 @@ def test_trainer_iteration_and_checkpoint_roundtrip(golden, tmp_path):
     m2.eval()
     tr2 = Trainer(m2, m2.cfg, steps_per_epoch=40)
     tr2.load_checkpoint(torch.load(path, weights_only=False))
-    assert tr2.step == 12
+    assert tr2.step == 12 and tr2.optimizer._step == 12              # the bias-correction counter travels with the checkpoint
     assert abs(float(tr2.train_step(batch)["loss"]) - nxt) < 1e-6
+    # the step AFTER the resume depends on the restored moments and step counter: the resumed run stays on the original one
+    after, after2 = float(tr.train_step(batch)["loss"]), float(tr2.train_step(batch)["loss"])
+    assert abs(after - after2) < 1e-5 * max(1.0, abs(after)), (after, after2)
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert _maxerr(a, b) <= 1e-6 * (1 + float(a.abs().max())), n
+    # torch.optim.AdamW's state layout: the reference's optimizer checkpoints load here and ours load there
+    st = ck["optimizer"]["state"]
+    assert all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in st.values()) and len(st) == len(list(m.parameters()))
+    topt = torch.optim.AdamW([{"params": [p]} for p in m.parameters()], lr=1e-3)
+    topt.load_state_dict(ck["optimizer"])
+    assert float(next(iter(topt.state.values()))["step"]) == 12.0
+    # one launch for all ~100 single-parameter groups (the reference's ClipOptimizerHook layout)
+    assert len(tr.optimizer.param_groups) > 50 and len(tr.optimizer._plans) == 1
 
 
 def test_bf16_weight_copy_cache_coherence(golden, monkeypatch):

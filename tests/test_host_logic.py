@@ -2,7 +2,9 @@
 import ctypes
 import json
 import os
+from types import SimpleNamespace
 
+import numpy as np
 import pytest
 import torch
 
@@ -156,3 +158,33 @@ def test_reference_tools_import_against_this_package(monkeypatch):
         spec.loader.exec_module(mod)              # runs the tool's imports and definitions, not its main()
         assert hasattr(mod, "evaluate_benchmark") and hasattr(mod, "main")
     assert sys.modules["simseg.models"].__file__.startswith(REPO)
+
+
+def test_pretrained_tower_weights_resample_pos_embed_or_fail_loudly(tmp_path, monkeypatch, golden):
+    """`pretrained: True` (both shipped YAMLs): a timm-named ViT state dict trained on another patch grid is loaded with its
+    pos_embed resampled to the model's grid (what timm.create_model(..., img_size=S) does, vit_builder.py:11) and head keys dropped;
+    missing weights raise instead of silently training from a random init, unless the caller opts out."""
+    from simseg.models import BACKBONE
+    from simseg.utils.interpolate_pe import interpolate_pos_embed
+    from simseg_amd.nn import ViT
+    argv = [a for a in TINY if "image_encoder.pretrained" not in a] + ["model.image_encoder.pretrained=True", "transforms.input_size=96"]
+    cfg = _cfg("simseg.vit-s.yaml", argv)
+    monkeypatch.delenv("SIMSEG_ALLOW_RANDOM_INIT", raising=False)
+    monkeypatch.setenv("SIMSEG_PRETRAINED_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="no weights were found"):
+        BACKBONE.get("vit_modelzoo")(cfg, img_size=96)
+    monkeypatch.setenv("SIMSEG_ALLOW_RANDOM_INIT", "1")
+    BACKBONE.get("vit_modelzoo")(cfg, img_size=96)
+    monkeypatch.delenv("SIMSEG_ALLOW_RANDOM_INIT")
+    src = ViT("vit_test_patch16", img_size=64)                    # "pretrained" on a 4x4 grid
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    sd["head.weight"], sd["head.bias"] = torch.zeros(10, 128), torch.zeros(10)
+    torch.save(sd, tmp_path / "vit_test_patch16.pth")
+    m = BACKBONE.get("vit_modelzoo")(cfg, img_size=96).model      # 6x6 grid
+    assert tuple(m.pos_embed.shape) == (1, 37, 128)
+    want = interpolate_pos_embed(sd["pos_embed"], m)
+    assert torch.equal(m.pos_embed.detach(), want)
+    assert torch.equal(m.blocks[1].mlp.fc2.weight.detach(), sd["blocks.1.mlp.fc2.weight"])
+    ref = golden("interp_pe")                                     # the resampling itself is pinned against the reference's function
+    fake = SimpleNamespace(patch_embed=SimpleNamespace(num_patches=18 * 18), pos_embed=torch.zeros(1, 1 + 18 * 18, 96))
+    assert np.allclose(interpolate_pos_embed(torch.from_numpy(ref["pe"]), fake).numpy(), ref["pe_18"], atol=1e-6)
