@@ -13,6 +13,7 @@ from simseg.models.backbones.builder import BACKBONE
 from simseg.models.criteria.losses.builder import LOSS
 from simseg.models.pipelines.builder import PIPELINE
 from simseg.utils import ENV
+from simseg_amd.heads import prefetch_gather
 from simseg_amd.nn import compute_dtype
 from simseg_amd.towers import ProjectPoolFn
 
@@ -81,6 +82,12 @@ class CLIPModel(nn.Module):
         return L2norm(emb, dim=-1) if self.cfg.model.projection.name == "simple" else emb
 
     # ---- loss / dispatch ----------------------------------------------------------------------------------------
+    def _prefetch(self, emb, embeddings):
+        """Start the global-batch all-gather of one tower's embeddings (the exchange step of mml_loss.py:60-64) as soon as they
+        exist, so that it runs under the other tower instead of in front of the loss."""
+        if embeddings is False and self.global_reduce and getattr(self.loss, "group", None) is not None:
+            prefetch_gather(emb, self.loss.group)
+
     def forward_loss(self, image_embeddings, text_embeddings, ignore_mask=None):
         if self.global_reduce:
             i2t_loss, i2t_acc = self.loss(image_embeddings, text_embeddings, ignore_mask=ignore_mask)
@@ -105,12 +112,22 @@ class CLIPModel(nn.Module):
             side.wait_stream(main)
             # (which tower is enqueued first makes no measurable difference: 126.2 vs 126.4 ms/step)
             img = self.forward_image_project(self.forward_image_feature(image))
+            self._prefetch(img, embeddings)          # the image embeddings travel while the text tower is still computing
             with torch.cuda.stream(side):
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
+                self._prefetch(txt, embeddings)
             main.wait_stream(side)
             txt.record_stream(main)
+            # The caption tensors were allocated under the main stream but are read by side-stream kernels in the forward AND, through
+            # the saved tensors of the text tower, in its backward.  Without this mark the caching allocator hands their memory back to
+            # the main stream the moment the last Python / autograd reference drops, while those kernels may still be queued (a batch
+            # that goes out of scope after the step: wrong word-embedding and first-layer gradients, found by the full-size parity test).
+            for t in (ids, mask):
+                if t.is_cuda:
+                    t.record_stream(side)
         else:
             img = self.forward_image_project(self.forward_image_feature(image))
+            self._prefetch(img, embeddings)
             txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
         if embeddings == "all":
             return [img, txt]

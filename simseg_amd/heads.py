@@ -1,5 +1,7 @@
 """Loss / similarity heads on the HIP kernels: differentiable embedding all-gather, global InfoNCE, the dense
 patch x class-text similarity map, and the retrieval recall computation."""
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
@@ -9,17 +11,54 @@ from . import ops
 F32 = torch.float32
 
 
+# Embedding all-gathers started ahead of their use (prefetch_gather): id(tensor) -> (weakref, input, output, work).  The exchange
+# of one tower's [Bl, P] embeddings then runs on the collective's own stream underneath the OTHER tower's kernels.
+_PREFETCH = {}
+
+
+def _gathered_shape(t, world):
+    return (world * t.shape[0],) + tuple(t.shape[1:])
+
+
+def prefetch_gather(tensor, group=None):
+    """Start the all-gather of `tensor`'s rows over `group` now (asynchronously, in rank order); the next GatherLayer /
+    all_gather_rows call on the same tensor object picks the result up instead of issuing its own collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    t = tensor.detach().contiguous()
+    out = torch.empty(_gathered_shape(t, world), device=t.device, dtype=t.dtype)
+    work = dist.all_gather_into_tensor(out, t, group=group, async_op=True)
+    _PREFETCH[id(tensor)] = (weakref.ref(tensor), t, out, work, group)
+
+
+def _take_prefetched(tensor, group):
+    ent = _PREFETCH.pop(id(tensor), None)
+    if ent is None or ent[0]() is not tensor or ent[4] is not group:
+        return None
+    ent[3].wait()                     # the compute stream waits for the collective's stream; the host does not block (RCCL)
+    if ent[2].is_cuda:                # allocated under the producing tower's stream, consumed on the loss's stream
+        ent[2].record_stream(torch.cuda.current_stream())
+    return ent[2]
+
+
 class GatherLayer(Function):
     """Differentiable all-gather of [Bl, ...] rows in rank order (simseg/utils/dist.py:323-354).
-    Forward: RCCL all-gather into one [W*Bl, ...] buffer.  Backward: the reference all-reduces the whole gathered
-    gradient and slices its own rows; a reduce-scatter delivers the same rows with 1/W of the traffic."""
+    Forward: all-gather into one [W*Bl, ...] buffer.  Backward: the reference all-reduces the whole gathered gradient and
+    slices its own rows (:347-354); a reduce-scatter delivers exactly those rows with 1/W of the traffic.  One code path for
+    every backend (RCCL on GPUs; gloo in the CPU tests implements both collectives too)."""
 
     @staticmethod
     def forward(ctx, tensor, group, rank):
         ctx.group, ctx.rank, ctx.bl = group, rank, tensor.shape[0]
         world = dist.get_world_size(group)
+        out = _take_prefetched(tensor, group)
+        if out is not None:
+            return out
         tensor = tensor.contiguous()
-        out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+        out = torch.empty(_gathered_shape(tensor, world), device=tensor.device, dtype=tensor.dtype)
         if world == 1:
             out.copy_(tensor)
         else:
@@ -32,22 +71,21 @@ class GatherLayer(Function):
         grad = grad.contiguous()
         if world == 1:
             return grad.clone(), None, None
-        if dist.get_backend(ctx.group) == "nccl":      # RCCL on ROCm
-            own = torch.empty((ctx.bl,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
-            dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=ctx.group)
-            return own, None, None
-        g = grad.clone()                               # gloo (CPU tests): no reduce_scatter_tensor
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g[ctx.rank * ctx.bl:(ctx.rank + 1) * ctx.bl].clone(), None, None
+        own = torch.empty((ctx.bl,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
+        dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        return own, None, None
 
 
 def all_gather_rows(tensor, group):
     """Non-differentiable variant (simseg/utils/dist.py:65-74, gather_backward=False)."""
     world = dist.get_world_size(group)
+    out = _take_prefetched(tensor, group)
+    if out is not None:
+        return out
     tensor = tensor.detach().contiguous()
     if world == 1:
         return tensor
-    out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+    out = torch.empty(_gathered_shape(tensor, world), device=tensor.device, dtype=tensor.dtype)
     dist.all_gather_into_tensor(out, tensor, group=group)
     return out
 

@@ -1,0 +1,122 @@
+"""Two data-parallel ranks on MI355X hardware: the exchange step of the contrastive loss (embedding all-gather forward,
+reduce-scatter backward: simseg/utils/dist.py:323-354) with the HIP loss / towers in between, against what the REFERENCE produced
+in a 2-process run (tests/golden/clip_train_ws2.npz).
+
+The GPU box has ONE GPU and RCCL refuses two ranks on one device, so the two processes share cuda:0 and talk over gloo (device
+tensors are staged by the backend); everything between the collectives is the product path.  `nccl` is tried first so that the
+same test exercises RCCL wherever two devices are visible."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLD, REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, backend, q):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if torch.cuda.device_count() >= world else 0), SIMSEG_AMD_COMPUTE="bf16")
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from simseg.utils import ENV
+        ENV.rank, ENV.size, ENV.local_rank = rank, world, dev.index
+        from simseg.models.criteria.losses.mml_loss import NCE
+        from test_gpu_model import _build
+        g = np.load(os.path.join(GOLD, f"clip_train_ws{world}.npz"))
+
+        def golden(name):
+            return np.load(os.path.join(GOLD, name + ".npz"))
+
+        res = {}
+        # (1) the loss alone, exact fp32: HIP NCEFn + GatherLayer on given embeddings, ignore mask on, temperature gradient
+        m = _build(golden).eval()                   # global_reduce=True, gather_backward=True (YAML defaults, as the fixture)
+        nce = m.loss
+        assert isinstance(nce, NCE) and nce.group is not None and nce.rank == rank
+        f1 = torch.from_numpy(g[f"r{rank}.nce_f1"]).to(dev).requires_grad_(True)
+        f2 = torch.from_numpy(g[f"r{rank}.nce_f2"]).to(dev).requires_grad_(True)
+        ign = torch.from_numpy(g[f"r{rank}.nce_ign"]).to(dev)
+        loss, acc = nce(f1, f2, ignore_mask=ign)
+        loss.backward()
+        res["nce"] = dict(loss=loss.item(), acc=acc.item(), g1=f1.grad.cpu().numpy(), g2=f2.grad.cpu().numpy(),
+                          gt=nce.temperature.grad.item())
+        nce.temperature.grad = None
+        # (2) the whole training forward/backward of this rank's batch (bf16 towers, prefetched gathers)
+        for two in ("0", "1"):
+            os.environ["SIMSEG_AMD_TWO_STREAMS"] = two
+            m.zero_grad(set_to_none=True)
+            batch = {k: torch.from_numpy(g[f"r{rank}.{k}"]).to(dev) for k in ("image", "input_ids", "attention_mask")}
+            loss_dict, a1, a2 = m(batch)
+            loss_dict["nce_loss"].backward()
+            torch.cuda.synchronize()
+            params = dict(m.named_parameters())
+            res[f"step{two}"] = dict(loss=loss_dict["nce_loss"].item(), a1=a1.item(), a2=a2.item(),
+                                     grads={k[len(f"r{rank}.grad."):]: params[k[len(f"r{rank}.grad."):]].grad.float().cpu().numpy()
+                                            for k in g.files if k.startswith(f"r{rank}.grad.")})
+        from simseg_amd import heads
+        res["prefetch_left"] = len(heads._PREFETCH)
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _cos(a, b):
+    a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_ranks_match_reference_two_process_run(world):
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(GOLD, f"clip_train_ws{world}.npz"))
+    for r in range(world):
+        o = out[r]["nce"]
+        np.testing.assert_allclose(o["loss"], float(g[f"r{r}.nce_loss"]), rtol=2e-5)
+        np.testing.assert_allclose(o["acc"], float(g[f"r{r}.nce_acc"]), atol=1e-6)
+        np.testing.assert_allclose(o["g1"], g[f"r{r}.nce_g1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o["g2"], g[f"r{r}.nce_g2"], rtol=1e-4, atol=1e-6)      # summed over both ranks' losses (reduce-scatter)
+        np.testing.assert_allclose(o["gt"], float(g[f"r{r}.nce_gt"]), rtol=1e-4)
+        assert out[r]["prefetch_left"] == 0                                                # every prefetched gather was consumed
+        for two in ("0", "1"):
+            s = out[r][f"step{two}"]
+            want = float(g[f"r{r}.loss"])
+            assert abs(s["loss"] - want) < 2e-2 * abs(want), (r, two, s["loss"], want)
+            assert abs(s["a1"] - float(g[f"r{r}.i2t_acc"])) < 1e-6 and abs(s["a2"] - float(g[f"r{r}.t2i_acc"])) < 1e-6
+            bad = []
+            for name, ours in s["grads"].items():
+                ref = g[f"r{r}.grad.{name}"]
+                c = _cos(ours, ref)
+                ratio = float(np.linalg.norm(ours) / (np.linalg.norm(ref) + 1e-30))
+                print(f"rank {r} two_streams={two} {name}: cos {c:.5f} norm ratio {ratio:.4f}")
+                if not (c > 0.99 and 0.9 < ratio < 1.1):
+                    bad.append((r, two, name, c, ratio))
+            assert not bad, bad

@@ -124,46 +124,65 @@ def _cos(a, b):
 
 def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
     """BASELINE config 3's towers at full width and depth (ViT-B/16 @224: T=197, BERT-base L=77, ragged masks), B=6: bf16 forward +
-    InfoNCE + backward on the HIP path against the fp32 CPU oracle on the same weights.  This is the dispatch region of the 256x256
-    GEMM kernel's smaller sibling, the one-round split-K weight gradients, the 4-wave attention blocks and every fused epilogue.
-    Bar: loss within 1e-2 relative; EVERY parameter gradient with cosine >= 0.999 and norm within 3 % of the oracle's."""
+    InfoNCE + backward on the HIP path against the fp32 CPU oracle on the same weights, under both tower schedules (one / two HIP
+    streams).  Exercises the GEMM dispatch at D=768, the split-K weight gradients, 3- and 4-wave attention blocks, every fused epilogue.
+
+    The bar.  A 12-layer bf16 network does not reproduce fp32 gradients to 0.999: torch's OWN bf16 autocast of the oracle (the
+    reference's mixed-precision recipe, run here on the host as the yardstick) reaches cosines of 0.983-0.997 on these tensors.  So:
+    loss within 1e-2 relative; every parameter gradient within 3 % in norm, cosine >= 0.985 AND at least as close to the fp32
+    gradient as torch's autocast-bf16 gradient of the same tensor is (1 - cos <= 1 - cos_autocast, with a 1e-3 floor).  BERT's key
+    bias is in the null space of the loss (softmax shift invariance): its gradient must be rounding noise (<= 1 % of the value-bias
+    gradient of the same block; the flash-style delta = rowsum(dO * O) leaves ~5e-4)."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
     from oracle import simseg_ref as R
     B, L = 6, 77
     ref = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=224), seed=12).eval()
-    m = _build_vitb(224)
-    missing, unexpected = m.load_state_dict(ref.state_dict(), strict=False)
-    assert not unexpected and all("position_ids" in k for k in missing)
-    m = m.cuda().eval()                                      # eval: no dropout, so gradients are comparable
     image = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(21))
     ids, mask = R.synthetic_text(B, L, 30522, seed=22, min_len=8)
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))     # (the GPU box reports 256 logical CPUs; oversubscribing them is 100x slower)
     want, _, _ = ref.forward_loss_local(image, ids, mask)
     want.backward()
-    loss = m({"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})[0]["nce_loss"]
-    loss.backward()
-    torch.cuda.synchronize()
-    assert abs(loss.item() - want.item()) < 1e-2 * abs(want.item()), (loss.item(), want.item())
-    refp = dict(ref.named_parameters())
-    worst_c, worst_r, bad = 1.0, 0.0, []
-    for n, p in m.named_parameters():
-        gr = refp[n].grad
-        assert p.grad is not None and gr is not None, n
-        assert torch.isfinite(p.grad).all(), n
-        if float(gr.norm()) < 1e-6:
-            # BERT's key bias: softmax is invariant to a per-query shift of the scores, so this gradient is zero in exact arithmetic
-            # (the oracle holds ~1e-9 of fp32 noise).  Ours must be noise too: small against the query bias gradient next to it.
-            assert n.endswith("attention.self.key.bias"), (n, float(gr.norm()))
-            qn = float(refp[n.replace(".key.", ".query.")].grad.norm())
-            assert float(p.grad.float().norm()) < 0.02 * qn, (n, float(p.grad.float().norm()), qn)
-            continue
-        c = _cos(p.grad, gr)
-        r = float(p.grad.double().norm().cpu() / gr.double().norm())
-        worst_c, worst_r = min(worst_c, c), max(worst_r, abs(r - 1))
-        if not (c >= 0.999 and abs(r - 1) <= 0.03):
-            bad.append((n, round(c, 5), round(r, 4)))
-    print(f"ViT-B/BERT-base bf16 gradients vs fp32 oracle: worst cosine {worst_c:.5f}, worst |norm ratio - 1| {worst_r:.4f}")
-    assert not bad, bad
+    g32 = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    ref.zero_grad(set_to_none=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        l16, _, _ = ref.forward_loss_local(image, ids, mask)
+    l16.backward()
+    yard = {n: _cos(p.grad, g32[n]) for n, p in ref.named_parameters()}
+    for two in ("0", "1"):
+        monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", two)
+        m = _build_vitb(224)
+        missing, unexpected = m.load_state_dict(ref.state_dict(), strict=False)
+        assert not unexpected and all("position_ids" in k for k in missing)
+        m = m.cuda().eval()                                      # eval: no dropout, so gradients are comparable
+        # the batch is a temporary: its device tensors die with the forward call unless the model keeps them alive correctly
+        loss = m({"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})[0]["nce_loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - want.item()) < 1e-2 * abs(want.item()), (loss.item(), want.item())
+        worst_c, worst_r, bad, null = 1.0, 0.0, [], []
+        for n, p in m.named_parameters():
+            gr = g32[n]
+            assert p.grad is not None, n
+            assert torch.isfinite(p.grad).all(), n
+            if float(gr.norm()) < 1e-6:
+                assert n.endswith("attention.self.key.bias"), (n, float(gr.norm()))
+                rel = float(p.grad.float().norm()) / float(g32[n.replace(".key.", ".value.")].norm())
+                null.append(rel)
+                if rel > 1e-2:
+                    bad.append((n, "null-space gradient / value-bias gradient", round(rel, 4)))
+                continue
+            c = _cos(p.grad, gr)
+            r = float(p.grad.double().norm().cpu() / gr.double().norm())
+            worst_c, worst_r = min(worst_c, c), max(worst_r, abs(r - 1))
+            if not (c >= 0.985 and abs(r - 1) <= 0.03 and (1 - c) <= max(1 - yard[n], 1e-3)):
+                bad.append((n, round(c, 5), round(r, 4), "autocast yardstick", round(yard[n], 5)))
+        print(f"two_streams={two}: ViT-B/BERT-base bf16 gradients vs fp32 oracle: worst cosine {worst_c:.5f} (torch autocast-bf16 yardstick: "
+              f"worst {min(v for k, v in yard.items() if not k.endswith('key.bias')):.5f}), worst |norm ratio - 1| {worst_r:.4f}; "
+              f"key-bias null-space size max {max(null):.2e}")
+        for b_ in bad:
+            print("BAD", b_)
+        assert not bad, f"{len(bad)} tensors outside the bar"
+        del m
 
 
 def test_vitb_512_window_forward_vs_oracle(monkeypatch):
@@ -176,7 +195,7 @@ def test_vitb_512_window_forward_vs_oracle(monkeypatch):
     m.load_state_dict(ref.state_dict(), strict=False)
     m = m.cuda().eval()
     x = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(3))
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))     # (the GPU box reports 256 logical CPUs; oversubscribing them is 100x slower)
     with torch.no_grad():
         want = ref(x)
         monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
