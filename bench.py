@@ -417,7 +417,8 @@ def main():
                 traffic = json.load(f)["per_kind"].get(dom, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError, KeyError):
             pass
-        kdesc = {"_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)", "": "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)"}["_L" if dom.endswith("_L") else ""]
+        kdesc = {"_P": "gemm_pp_kernel (256x256 tile, two wave groups in ping-pong, direct-to-LDS half-tile ring)",
+                 "_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)"}.get(dom[-2:], "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)")
         out = {
             "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",
             "value_is": "training image-text pairs/s over all ranks; the zero-shot-seg eval rate is reported in seg_eval", "n_gpus": world,

@@ -22,7 +22,7 @@ def _c(t):
 
 
 def set_gemm_variant(v):
-    """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS kernel (tests / benchmarks only)."""
+    """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring, 3 = 256x256 ping-pong (tests / benchmarks only)."""
     call("simseg_set_gemm_variant", int(v))
 
 
@@ -56,12 +56,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         e1.record()
         kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
         kind += "_o32" if out.dtype == torch.float32 else "_o16"
-        t256 = ((M + 255) // 256) * ((N + 255) // 256)
-        if a.dtype == torch.bfloat16 and K % 64 == 0 and M >= 256 and N >= 128 and (
-                (not trans_a and K >= 768 and t256 >= 256) or
-                (trans_a and accumulate and splitk > 1 and out.dtype == torch.float32 and M % 256 == 0 and N % 256 == 0 and t256 <= 128
-                 and (K // 64) // (256 // t256) >= 16)):
-            kind += "_L"          # the dispatcher's rules for the 256x256 direct-to-LDS kernel (csrc/gemm.hip dispatch_bf16)
+        kind += {1: "", 2: "_L", 3: "_P"}[raw("simseg_gemm_last_variant")]      # the kernel the library actually launched
         PROFILE.append((kind, 2.0 * M * N * K, e0, e1))
     return out
 

@@ -98,7 +98,7 @@ def test_gemm_bf16_layouts(ops, ta, tb, M, N, K):
     _close(ops.gemm(a, b, trans_a=ta, trans_b=tb), ref, 1e-2, f"bf16 ta={ta} tb={tb} bf16 out")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 520, 192), (256, 136, 64), (2048, 768, 768), (16640, 768, 192)])
 def test_gemm_bf16_large_tile_kernel(ops, variant, ta, tb, M, N, K):
