@@ -96,6 +96,11 @@ int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 
+/* Kernel selection for benchmarking / tests: 0 auto (bf16 sequences of <= 128 tokens run the "resident" forward kernel that holds a
+ * whole head's K / V in LDS), 1 = always the streaming ring kernel, 4 = resident for every T <= 256 (2 / 3: timing ablations). */
+int simseg_set_attention_variant(int v);
+int simseg_debug_attn_occupancy(int64_t T);
+
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]
  * (log2 domain, optional) is saved for the backward.  dtype 0 = exact fp32 MFMA, 1 = bf16 MFMA.  drop_p > 0 applies

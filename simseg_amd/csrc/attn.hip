@@ -12,6 +12,7 @@
 // score registers; V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (bf16) or plain b32
 // reads (fp32).  fp32 path = v_mfma_f32_32x32x2_f32 (exact), bf16 path = v_mfma_f32_32x32x16_bf16.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -25,6 +26,7 @@ struct AttnParams {
     unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
     // backward
     const void* dout; const float* delta; void* dqkv;
+    int dbg;            // resident kernels, benchmarking only: 2 = skip the K/V copy, 3 = skip the tile loop
 };
 
 // online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
@@ -79,6 +81,67 @@ __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias,
             ps += p;
         }
     lsum = lsum * alpha + ps;
+}
+
+// Lean online-softmax update for the bf16 kernels, where the softmax VALU work - not the MFMAs - sets the pace (a 64-key tile
+// is 16 MFMAs = 512 matrix-pipe cycles per wave against ~300 VALU instructions in softmax_tile).  Three savings:
+//   * interior tiles (no key bias, no padding) take the maximum of the RAW scores and fold the scale into the exponent's FMA:
+//     one max, one FMA, one exp2 and one add per score - no compare / select, no separate multiply and subtract;
+//   * the running maximum is only raised (and O, l rescaled) when some row's tile maximum exceeds it by more than RESCALE_THR
+//     (log2 units): probabilities then reach at most 2^THR, which bf16 (constant relative precision) and the fp32 accumulators
+//     carry without loss of accuracy, and the 32-multiply rescale of O disappears from almost every tile.  The decision is
+//     wave-uniform, every quantity at the old maximum (O, l) is rescaled exactly once, P is formed after the decision;
+//   * maxima and sums run as four independent chains.
+// `o` holds the UNNORMALISED output accumulators; on return s holds P (to be multiplied into o by the caller).
+constexpr float RESCALE_THR = 6.0f;
+
+template <bool BIAS, bool EDGE>
+__device__ __forceinline__ void softmax_tile_lean(f32x16 (&s)[2], const float* kbias, int h2, float c, float& m, float& lsum,
+                                                  f32x16 (&o)[2], int klim) {
+    float mx[4] = {NEG, NEG, NEG, NEG};
+    constexpr bool scaled = BIAS || EDGE;          // s is rewritten as the scaled, biased / masked score
+    if (scaled) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                float x;
+                if (BIAS) x = fmaf(s[kb][r], c, kbias[key]);
+                else x = key < klim ? s[kb][r] * c : NEG;
+                s[kb][r] = x;
+                mx[r & 3] = fmaxf(mx[r & 3], x);
+            }
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[r & 3] = fmaxf(mx[r & 3], s[kb][r]);
+    }
+    float tmax = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    if (!scaled) tmax *= c;                         // c > 0
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (!__all(tmax <= m + RESCALE_THR)) {          // wave-uniform
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    const float nm = -m;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(scaled ? s[kb][r] + nm : fmaf(s[kb][r], c, nm));
+            s[kb][r] = pr;
+            ps[r & 3] += pr;
+        }
+    lsum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,7 +424,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
     const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
     int cur = 0;
-    for (int it = 0; it < nt; ++it) {
+    // one 64-key tile; EDGE = the last tile (keys past T masked): peeled out of the loop so that the loop body carries a single,
+    // branch-free softmax (two copies behind a branch pushed the kernel over its 168 registers)
+    auto tile = [&](int it, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const int kv0 = it * KT;
         dt0 = __builtin_readcyclecounter();
         // tile `it` landed (this wave's share; the barrier extends it to every wave's), tile it+1 may still be in flight
@@ -380,7 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
         // all eight K fragments are requested before the first MFMA (one LDS round trip per tile instead of one per
         // MFMA), and the two key blocks' accumulation chains are interleaved so no MFMA waits on its predecessor
-        const bool two = kv0 + 32 < T;              // else the second 32-key block is all padding (its P is exactly 0)
+        const bool two = !EDGE || kv0 + 32 < T;     // else the second 32-key block is all padding (its P is exactly 0)
         bf16x8 kf[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) kf[i] = ld_bf16x8(sk + (i >> 2) * 32 * 128 + krow + (((2 * (i & 3) + h2) ^ ksw) << 4));
@@ -400,14 +466,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
         }
-        float alpha;
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[1] += t1 - dt0; dt0 = t1; }
-        if (MASK) softmax_tile<true, true>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, alpha);
-        else softmax_tile<true, false>(s, nullptr, h2, p.scale_log2e, m, lsum, alpha, T - kv0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        if (MASK) softmax_tile_lean<true, false>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, o, KT);
+        else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0);
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[2] += t1 - dt0; dt0 = t1; }
         if (DROP) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
 #pragma unroll
@@ -444,7 +505,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         if (DBG) { asm volatile("" ::"v"(o[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[3] += t1 - dt0; dt0 = t1; }
         cur = cur + 1 == GNS ? 0 : cur + 1;
-    }
+    };
+    for (int it = 0; it < nt - 1; ++it) tile(it, std::false_type{});
+    tile(nt - 1, std::true_type{});
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
     if (q < T) {
@@ -474,6 +537,204 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         d[8 + blin * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
         d[8 + blin * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 forward, short sequences (T <= 256: ViT-B @224, every BERT caption): "resident" form.
+// One block = one (batch, head); ALL of the head's K and V (T x 64 x 2 x 2 B <= 64 KiB) are copied global -> LDS once
+// (global_load_lds, same swizzled stage images as the ring kernel), then every wave walks its 32-query tile over all
+// key tiles with NO further barrier and no staging in the loop: the waves of a block - and the 2-4 blocks resident
+// on a CU - drift apart, so the softmax VALU work of one wave runs under the MFMAs of another, and one block's load
+// phase under the other blocks' compute.  (The ring kernel spent 8.3 k of its 22.5 k cycles per block staging the first
+// tile and ~660 cycles per tile in wait + barrier: profiles/r1_attn_timeline.txt.)
+// ------------------------------------------------------------------------------------------------
+constexpr int RES_MAXT = 256;
+constexpr int RES_AUTO_T = 128;          // measured (tools/dbg_attn_res.py): resident 56 vs ring 61 us at T=77, 20 vs 31 at T=25, 214 vs 209 at T=197
+
+// LDS of the resident kernels: [K rows8 x 128 B][V rows8 x 128 B][key bias], rows8 = T rounded up to 8 (rows T..rows8-1 repeat row
+// T-1).  Row r of K holds its eight 16-byte chunks at slots c ^ k_swz(r), V at c ^ v_swz(r) (the images the ring kernel's fragment
+// reads expect; both swizzles have a period that divides 32, so stage-relative and absolute row indices give the same slot).  The
+// last, partial tile clamps its fragment rows to rows8-1 (finite values; those keys are masked / have probability exactly 0), so
+// nothing is read past the matrices and a ViT-B head (T = 197) takes 51 200 B: three blocks per CU at the 1 280-byte LDS
+// allocation granule (a 3 KiB guard behind V cost the third block: 202 -> 225 us).
+__device__ __forceinline__ int res_rows8(int T) { return (T + 7) & ~7; }
+
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_bf16_res_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    const int bh_ = blockIdx.x;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int HD = p.H * 64;
+    const int nt = (T + KT - 1) / KT, q32 = (T + 31) / 32;
+    const int rows8 = res_rows8(T), np = rows8 >> 3;                  // 1-KiB pieces per matrix
+    char* ldsK = lds;
+    char* ldsV = lds + rows8 * 128;
+    float* kb_all = reinterpret_cast<float*>(ldsV + rows8 * 128);
+
+    // K rows first (the first MFMAs need only K), then V rows; rows past T re-read row T-1
+    for (int piece = (p.dbg == 2 ? 2 * np : wave); piece < 2 * np; piece += nw) {
+        const int isv = piece >= np;
+        const int pp = isv ? piece - np : piece;
+        const int r = pp * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (isv ? v_swz(r) : k_swz(r));
+        const int key = r < T ? r : T - 1;
+        const bf16_t* src = base + (long)key * RS + (isv + 1) * HD + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)((isv ? ldsV : ldsK) + pp * 1024), 16, 0, 0);
+    }
+    if (MASK) {
+        for (int key = tid; key < nt * KT; key += nthr)
+            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+    }
+    // this wave's query tiles: wave, wave + nw (T <= 256 and nw = min(4, q32): at most two).  The first tile's Q rows are fetched
+    // with the K / V copies; the second tile's replace them as soon as the first pass has formed its last scores.
+    bf16x8 qr[4];
+    auto load_q = [&](int qt) {
+        const int q = qt * 32 + ql;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { u32x4 v; bf16x8 hh; } u;
+            u.v = (u32x4){0u, 0u, 0u, 0u};
+            if (q < T) u.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
+            qr[kk] = u.hh;
+        }
+    };
+    load_q(wave);
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int krow = ql * 128, ksw = k_swz(ql);
+    const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
+    const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(qr[0]), "v"(qr[1]), "v"(qr[2]), "v"(qr[3]));
+    __syncthreads();
+
+#pragma unroll 1
+    for (int qt = wave; qt < q32; qt += nw) {
+        const int q = qt * 32 + ql;
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+        float m = NEG, lsum = 0.f;
+        // one 64-key tile; EDGE = the last, partial tile (keys past T masked; its second 32-key block may be all padding)
+        auto tile = [&](int it, auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            const int kv0 = it * KT;
+            const char* sk = ldsK + kv0 * 128;
+            const char* sv = ldsV + kv0 * 128;
+            const bool two = !EDGE || kv0 + 32 < T;     // else the second 32-key block is all padding (its P is exactly 0)
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            {
+                bf16x8 kf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (!EDGE) {
+                        kf[i] = ld_bf16x8(sk + (i >> 2) * 32 * 128 + krow + (((2 * (i & 3) + h2) ^ ksw) << 4));
+                    } else {
+                        int r = kv0 + (i >> 2) * 32 + ql;
+                        r = r < rows8 ? r : rows8 - 1;
+                        kf[i] = ld_bf16x8(ldsK + r * 128 + (((2 * (i & 3) + h2) ^ k_swz(r)) << 4));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // all fragments requested before the first MFMA (one LDS round trip, not eight)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
+                    if (two) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
+                }
+            }
+            if (EDGE && qt + nw < q32) load_q(qt + nw);      // Q of the next pass: lands under this tile's softmax, PV and stores
+            // the transposed V fragments are requested before the softmax arithmetic: their LDS round trip runs under it
+            bf16x8 vf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {     // i = kb*4 + s2*2 + db
+                if (!EDGE) {
+                    const int roff = ((i >> 2) * 32 + 16 * ((i >> 1) & 1)) * 128 + vrow;
+                    const int coff = ((((i & 1) * 4 + vch) ^ vsw) << 4) + vsub;
+                    vf[i] = tr_frag(sv + roff + coff, 8 * 128);
+                } else {
+                    const int r0 = kv0 + (i >> 2) * 32 + 16 * ((i >> 1) & 1) + 4 * h2 + (a16 >> 2);
+                    const int ra = r0 < rows8 ? r0 : rows8 - 1, rb = r0 + 8 < rows8 ? r0 + 8 : rows8 - 1;
+                    const char* pa = ldsV + ra * 128 + ((((i & 1) * 4 + vch) ^ v_swz(ra)) << 4) + vsub;
+                    const char* pb = ldsV + rb * 128 + ((((i & 1) * 4 + vch) ^ v_swz(rb)) << 4) + vsub;
+                    union { struct { s16x4 lo, hi; } h; bf16x8 v; } u;
+                    u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa));
+                    u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
+                    vf[i] = u.v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MASK) softmax_tile_lean<true, false>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, o, KT);
+            else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0);
+            if (DROP) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                        const unsigned idx = ((unsigned)bh_ * T + q) * T + key;                 // < 2^32: checked by the host
+                        s[kb][r] = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !two) break;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
+                }
+            }
+        };
+        if (p.dbg != 3) {
+            for (int it = 0; it < nt - 1; ++it) tile(it, std::false_type{});
+            tile(nt - 1, std::true_type{});            // (a full last tile goes through the masked form too: same result)
+        }
+        const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (q < T) {
+            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * T + q) * p.H * 64 + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = db * 32 + 8 * r4 + 4 * h2;
+                    bf16x4 v = {(bf16_t)(o[db][4 * r4] * inv), (bf16_t)(o[db][4 * r4 + 1] * inv), (bf16_t)(o[db][4 * r4 + 2] * inv), (bf16_t)(o[db][4 * r4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + d) = v;
+                }
+            if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+        }
+    }
+}
+
+__host__ int res_smem(int T, bool mask) { return 2 * ((T + 7) & ~7) * 128 + (mask ? ((T + KT - 1) / KT) * KT * 4 : 0); }
+
+template <bool DROP, bool MASK>
+int launch_fwd_res(const AttnParams& p, hipStream_t stream) {
+    const int q32 = (p.T + 31) / 32;
+    static bool configured = false;
+    auto kern = attn_fwd_bf16_res_kernel<DROP, MASK>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, res_smem(RES_MAXT, true));
+        if (e != hipSuccess) return simseg_set_error("attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * p.H)), dim3((q32 < 4 ? q32 : 4) * 64), res_smem(p.T, MASK), stream, p);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -828,6 +1089,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 // for 6-wave blocks) - fewer waves per barrier and per staged K/V tile beat a perfectly filled last block.
 int attn_waves_per_block(int q32) { return q32 <= 4 ? q32 : 4; }
 
+int g_attn_variant = 0;          // tests / benchmarks: 1 = always the streaming (ring) kernels
+
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
                 uint64_t seed, float drop_p) {
     SS_CHECK(qkv, "attention: null qkv");
@@ -838,6 +1101,7 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = (const long*)mask; p.B = (int)B; p.T = (int)T; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.dbg = g_attn_variant;
     p.drop_seed = seed;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -845,6 +1109,19 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
 }
 
 }  // namespace
+
+// debug: resident blocks per CU the runtime predicts for the resident forward kernel at sequence length T
+extern "C" int simseg_debug_attn_occupancy(int64_t T) {
+    int n = -1;
+    const int q32 = (int)((T + 31) / 32);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_bf16_res_kernel<false, false>, (q32 < 4 ? q32 : 4) * 64, res_smem((int)T, false));
+    return n;
+}
+
+extern "C" int simseg_set_attention_variant(int v) {
+    g_attn_variant = v;
+    return 0;
+}
 
 // ctx[B,T,H*64] = softmax(q k^T * scale + keymask) v  from packed qkv[B,T,3,H,64]; lse[B,H,T] (log2 domain) optional.
 extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B,
@@ -861,7 +1138,13 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
     if (dtype == 0)
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
-    else
+    else if ((T <= RES_AUTO_T || (g_attn_variant >= 2 && T <= RES_MAXT)) && g_attn_variant != 1) {
+        int rc;
+        if (p.drop_thresh) rc = launch_fwd_res<true, true>(p, (hipStream_t)stream);
+        else if (p.mask) rc = launch_fwd_res<false, true>(p, (hipStream_t)stream);
+        else rc = launch_fwd_res<false, false>(p, (hipStream_t)stream);
+        if (rc) return rc;
+    } else
         if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
         else if (p.mask) hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);

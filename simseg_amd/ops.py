@@ -26,6 +26,11 @@ def set_gemm_variant(v):
     call("simseg_set_gemm_variant", int(v))
 
 
+def set_attention_variant(v):
+    """0 auto (bf16 sequences of <= 256 tokens on the resident kernels), 1 = always the streaming ring kernels (tests / benchmarks only)."""
+    call("simseg_set_attention_variant", int(v))
+
+
 PROFILE = None   # bench.py sets this to a list to time every GEMM launch with events on the launch stream
 
 

@@ -384,6 +384,43 @@ def test_attention_bwd(ops, T):
         assert float(g[1, 9:, 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T", [77, 197, 600])
+def test_attention_deferred_rescale_branch(ops, T):
+    """The online softmax raises its running maximum (and rescales O, l) only when a tile's maximum exceeds it by more than a
+    threshold - a rare, data-dependent branch that bounded random scores never take after the first tile.  Force it: a few
+    late keys are made collinear with a few queries so that those rows' maxima jump by far more than the threshold in the second,
+    third, ... tile, in some lanes of a wave only.  Forward (both kernels: resident for T <= 256, ring above / when forced) and the
+    log-sum-exp the backward consumes, against fp32 torch."""
+    B, H = 2, 3
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=0.6, dtype=torch.bfloat16)
+    v5 = qkv.view(B, T, 3, H, 64)
+    for j, (qi, ki, amp) in enumerate(((3, T - 2, 6.0), (T // 2, 70 if T > 70 else T - 1, 9.0), (T - 1, T // 2 + 1, 4.0), (40, 66 if T > 66 else 5, 12.0))):
+        v5[j % B, ki, 1, j % H] = (v5[j % B, qi, 0, j % H].float() * amp).bfloat16()          # score ~ amp * |q|^2 / 8 >> threshold
+    mask = None
+    if T <= 77:
+        mask = torch.ones(B, T, dtype=torch.long, device="cuda")
+        mask[1, T - 9:] = 0
+    ref = _attn_ref(qkv, H, mask, 0.125)
+    q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) * 0.125
+    if mask is not None:
+        sc = sc.masked_fill(mask[:, None, None, :] == 0, -1e30)
+    assert float(sc.max()) > 25.0                                   # the spikes are there (log2 units: > 36 >> 6)
+    want_lse = torch.logsumexp(sc, -1) / math.log(2)
+    for variant in (4, 1):                                           # 4: resident kernel for every T <= 256, 1: ring kernel
+        ops.set_attention_variant(variant)
+        try:
+            out, lse = ops.attention_fwd(qkv, H, mask, save_lse=True)
+        finally:
+            ops.set_attention_variant(0)
+        _close(out, ref, 1.5e-2, f"attention fwd with late maxima T={T} variant={variant}")
+        _close(lse, want_lse, 1e-2, "lse (log2)")
+    dout = _rand(B, T, H * 64, seed=T + 1, dtype=torch.bfloat16)
+    x = qkv.float().requires_grad_(True)
+    _attn_ref(x, H, mask, 0.125).backward(dout.float())
+    _close(ops.attention_bwd(qkv, out, dout, lse, H, mask), x.grad, 2e-2, f"attention bwd with late maxima T={T}")
+
+
 @pytest.mark.parametrize("T", [1, 33, 64, 65, 129, 1025])
 def test_attention_edge_lengths(ops, T):
     """Tile edges (one token, one over a 32 / 64 boundary, the 512^2 window) with a (batch x head) count that is not a multiple of

@@ -38,7 +38,7 @@ def main():
         byts = 64 * 1024 * 512 * proj.element_size() + 171 * 512 * proj.element_size() + 64 * 1024 * 171 * 4
         out[f"sim_map_{dt}"] = {"shape": "[65536,512]x[171,512]^T", "ms": round(s * 1e3, 4), "tflops": round(fl / s / 1e12, 1),
                                 "frac_mfma_peak": round(fl / s / PEAK[dt], 4), "GBps": round(byts / s / 1e9, 1), "frac_hbm_8TBps": round(byts / s / 8e12, 4)}
-        for name, B, T in (("vitb_224", 512, 197), ("vitb_512", 16, 1025)):
+        for name, B, T in (("vitb_224", 512, 197), ("bert_77", 512, 77), ("vitb_512", 16, 1025)):
             H = 12
             qkv = torch.randn(B, T, 3 * H * 64, device="cuda", generator=g).to(tdt)
             s = timeit(lambda: ops.attention_fwd(qkv, H, None, save_lse=(dt == "bf16")))
