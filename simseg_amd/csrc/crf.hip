@@ -1,0 +1,394 @@
+// Fully connected CRF refinement of the zero-shot segmentation candidate maps on the device.
+//
+// Replaces `dense_crf` of the reference's tool (tools/seg_evaluation.py:31-54, called at :153 for every visited candidate class):
+//     DenseCRF2D(W, H, 2); U = -log([1 - p, p] + 1e-8); addPairwiseGaussian(sxy=3, compat=3);
+//     addPairwiseBilateral(sxy=40, srgb=13, rgbim, compat=10); inference(3); argmax
+// i.e. Kraehenbuehl & Koltun's mean-field inference with Potts compatibilities and two Gaussian kernels, each applied through a
+// permutohedral lattice (Adams, Baek & Davis 2010) with symmetric normalisation - restated for the CPU in oracle/crf_ref.py
+// (pydensecrf itself is not available in this image; the restatement is pinned against an exact O(N^2) mean-field).
+//
+// HBM-bound byte / index work (no MFMA): per image the two lattices are built once and shared by all candidate maps (channels):
+//   simplex   : one thread per pixel - elevate the feature vector, round to the remainder-0 point, rank, barycentric weights; the
+//               d+1 simplex vertices are packed into one 64-bit key each and inserted into an open-addressing hash table (CAS)
+//   assign    : every occupied slot draws a dense lattice-point id; neighbours: 2 (d+1) hash look-ups per lattice point
+//   filter    : splat (atomic adds of weight x value, channels innermost), d+1 blur passes over the lattice points
+//               (new = old + (n1 + n2) / 2, ping-pong buffers, row 0 = the zero "missing neighbour"), slice
+//   mean field: Q1 = sigmoid(t1 - t0), t_l = -U_l + sum_k w_k n_k K_k(n_k Q_l); with two labels Q0 = 1 - Q1, so
+//               K(n Q0) = K(n) - K(n Q1): ONE filter of the C class-1 channels per kernel and iteration, K(n) once per lattice.
+// Scalar constants of the lattice filter (alpha, the un-normalised blur) cancel in n = 1 / sqrt(K 1): kept as in the library.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned long long CRF_EMPTY = ~0ull;
+constexpr int CRF_MAXC = 8;
+
+template <int D> struct KeyBits { static constexpr int B = D <= 2 ? 16 : 12; };
+
+template <int D>
+__device__ __forceinline__ unsigned long long crf_pack(const int (&k)[D]) {
+    constexpr int B = KeyBits<D>::B;
+    unsigned long long key = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) key |= (unsigned long long)((unsigned)(k[i] + (1 << (B - 1))) & ((1u << B) - 1)) << (i * B);
+    return key;
+}
+template <int D>
+__device__ __forceinline__ void crf_unpack(unsigned long long key, int (&k)[D]) {
+    constexpr int B = KeyBits<D>::B;
+#pragma unroll
+    for (int i = 0; i < D; ++i) k[i] = (int)((key >> (i * B)) & ((1u << B) - 1)) - (1 << (B - 1));
+}
+__device__ __forceinline__ unsigned crf_hash(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (unsigned)x;
+}
+__device__ __forceinline__ int crf_insert(unsigned long long* hkeys, unsigned mask, unsigned long long key) {
+    unsigned slot = crf_hash(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(hkeys + slot, CRF_EMPTY, key);
+        if (prev == CRF_EMPTY || prev == key) return (int)slot;
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ __forceinline__ int crf_find(const unsigned long long* hkeys, const int* hid, unsigned mask, unsigned long long key) {
+    unsigned slot = crf_hash(key) & mask;
+    for (;;) {
+        const unsigned long long cur = hkeys[slot];
+        if (cur == key) return hid[slot];
+        if (cur == CRF_EMPTY) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// Permutohedral::init, one thread per pixel (pixel i = y * W + x).  D = 2: (x, y) / sxy;  D = 5: (x, y) / sxy, rgb / srgb.
+template <int D>
+__global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int H, int W, float inv_sxy, float inv_srgb,
+                                                          unsigned long long* __restrict__ hkeys, unsigned mask, int* __restrict__ off,
+                                                          float* __restrict__ bary, int* __restrict__ overflow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    float f[D];
+    f[0] = (float)(i % W) * inv_sxy;
+    f[1] = (float)(i / W) * inv_sxy;
+    if constexpr (D == 5) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[2 + c] = (float)rgb[(long)i * 3 + c] * inv_srgb;
+    }
+    const float inv_std_dev = sqrtf(2.0f / 3.0f) * (D + 1);
+    float elevated[D + 1];
+    float sm = 0.f;
+#pragma unroll
+    for (int j = D; j > 0; --j) {
+        const float cf = f[j - 1] * (1.0f / sqrtf((float)(j * (j + 1))) * inv_std_dev);
+        elevated[j] = sm - (float)j * cf;
+        sm += cf;
+    }
+    elevated[0] = sm;
+    const float down_factor = 1.0f / (D + 1), up_factor = (float)(D + 1);
+    float rem0[D + 1];
+    float fsum = 0.f;
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+        const float v = down_factor * elevated[k];
+        const float up = ceilf(v) * up_factor, down = floorf(v) * up_factor;
+        rem0[k] = (up - elevated[k] < elevated[k] - down) ? up : down;
+        fsum += rem0[k] * down_factor;
+    }
+    const int isum = (int)rintf(fsum);
+    int rank[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) rank[k] = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = a + 1; b <= D; ++b) {
+            if (elevated[a] - rem0[a] < elevated[b] - rem0[b]) rank[a]++;
+            else rank[b]++;
+        }
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+        rank[k] += isum;
+        if (rank[k] < 0) { rank[k] += D + 1; rem0[k] += up_factor; }
+        else if (rank[k] > D) { rank[k] -= D + 1; rem0[k] -= up_factor; }
+    }
+    float bc[D + 2];
+#pragma unroll
+    for (int k = 0; k <= D + 1; ++k) bc[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k <= D; ++k) {
+        const float v = (elevated[k] - rem0[k]) * down_factor;
+        // (rank is a small runtime value: select by comparison so the array stays in registers)
+#pragma unroll
+        for (int t = 0; t <= D + 1; ++t) {
+            if (t == D - rank[k]) bc[t] += v;
+            if (t == D + 1 - rank[k]) bc[t] -= v;
+        }
+    }
+    bc[0] += 1.0f + bc[D + 1];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        int key[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            key[k] = (int)rintf(rem0[k]) + (rank[k] <= D - r ? r : r - (D + 1));        // canonical simplex, remainder r
+            bad = bad || key[k] < -(1 << (KeyBits<D>::B - 1)) || key[k] >= (1 << (KeyBits<D>::B - 1));
+        }
+        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key));       // hash slot for now; dense id after crf_assign
+        bary[(long)i * (D + 1) + r] = bc[r];
+    }
+    if (bad) atomicExch(overflow, 1);
+}
+
+__global__ __launch_bounds__(256) void crf_assign_kernel(const unsigned long long* __restrict__ hkeys, int cap, int* __restrict__ hid,
+                                                         unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= cap) return;
+    const unsigned long long k = hkeys[s];
+    if (k == CRF_EMPTY) return;
+    const int id = atomicAdd(M, 1);
+    hid[s] = id;
+    pkeys[id] = k;
+}
+
+__global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off, const int* __restrict__ hid, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) off[i] = hid[off[i]];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long long* __restrict__ pkeys, const int* __restrict__ M,
+                                                            const unsigned long long* __restrict__ hkeys, const int* __restrict__ hid,
+                                                            unsigned mask, int* __restrict__ nb, int mmax) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *M) return;
+    int key[D];
+    crf_unpack<D>(pkeys[i], key);
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+        int k1[D], k2[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { k1[k] = key[k] - 1; k2[k] = key[k] + 1; }
+        if (j < D) { k1[j] = key[j] + D; k2[j] = key[j] - D; }
+        nb[((long)j * mmax + i) * 2 + 0] = crf_find(hkeys, hid, mask, crf_pack<D>(k1));
+        nb[((long)j * mmax + i) * 2 + 1] = crf_find(hkeys, hid, mask, crf_pack<D>(k2));
+    }
+}
+
+// splat: val[(off + 1) * C + c] += bary * scale_i * in[i * C + c]   (in == nullptr: the constant 1, one channel)
+template <int D>
+__global__ __launch_bounds__(256) void crf_splat_kernel(const float* __restrict__ in, const float* __restrict__ scale, const int* __restrict__ off,
+                                                        const float* __restrict__ bary, float* __restrict__ val, int N, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float v[CRF_MAXC];
+    const float sc = scale ? scale[i] : 1.0f;
+    for (int c = 0; c < C; ++c) v[c] = (in ? in[(long)i * C + c] : 1.0f) * sc;
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * C;
+        const float w = bary[(long)i * (D + 1) + r];
+        for (int c = 0; c < C; ++c) atomicAdd(val + o + c, w * v[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ nbj,
+                                                       const int* __restrict__ M, int C) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t / C;
+    const int c = (int)(t % C);
+    if (i >= *M) return;
+    const int n1 = nbj[i * 2] + 1, n2 = nbj[i * 2 + 1] + 1;                  // -1 -> row 0 (zeros)
+    dst[(i + 1) * C + c] = src[(i + 1) * C + c] + 0.5f * (src[(long)n1 * C + c] + src[(long)n2 * C + c]);
+}
+
+// slice: out[i * C + c] = scale_i * alpha * sum_r bary * val[(off + 1) * C + c]
+template <int D>
+__global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ val, const float* __restrict__ scale, const int* __restrict__ off,
+                                                        const float* __restrict__ bary, float* __restrict__ out, int N, int C, int sqrt_norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
+    float acc[CRF_MAXC];
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int r = 0; r <= D; ++r) {
+        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * C;
+        const float w = bary[(long)i * (D + 1) + r];
+        for (int c = 0; c < C; ++c) acc[c] += w * val[o + c] * alpha;
+    }
+    const float sc = scale ? scale[i] : 1.0f;
+    for (int c = 0; c < C; ++c) {
+        float v = acc[c] * sc;
+        if (sqrt_norm) v = 1.0f / sqrtf(v + 1e-20f);                          // norm = 1 / sqrt(K 1 + 1e-20)
+        out[(long)i * C + c] = v;
+    }
+}
+
+// U = -log([1 - p, p] + 1e-8);  Q = softmax(-U)   (prob [C][N] -> q1 [N][C], u [N][C][2])
+__global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__ prob, float* __restrict__ q1, float* __restrict__ u, int N, int C) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)N * C) return;
+    const long i = t / C;
+    const int c = (int)(t % C);
+    const float p = prob[(long)c * N + i];
+    const float u0 = -logf((1.0f - p) + 1e-8f), u1 = -logf(p + 1e-8f);
+    u[t * 2] = u0; u[t * 2 + 1] = u1;
+    const float t0 = -u0, t1 = -u1, mx = fmaxf(t0, t1);
+    const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
+    q1[t] = e1 / (e0 + e1);
+}
+
+// t_l = -U_l + wg * fg_l + wb * fb_l with f_1 = filtered Q1, f_0 = K(n) n - f_1;  Q1 = softmax;  last iteration: mask = 255 * (t1 > t0)
+__global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict__ u, const float* __restrict__ fg, const float* __restrict__ fb,
+                                                         const float* __restrict__ kng, const float* __restrict__ knb, float wg, float wb,
+                                                         float* __restrict__ q1, unsigned char* __restrict__ mask, float* __restrict__ q_out,
+                                                         int N, int C) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)N * C) return;
+    const long i = t / C;
+    const int c = (int)(t % C);
+    const float g1 = fg[t], b1 = fb[t];
+    const float t0 = -u[t * 2] + wg * (kng[i] - g1) + wb * (knb[i] - b1);
+    const float t1 = -u[t * 2 + 1] + wg * g1 + wb * b1;
+    const float mx = fmaxf(t0, t1);
+    const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
+    const float q = e1 / (e0 + e1);
+    q1[t] = q;
+    if (mask) mask[(long)c * N + i] = (e1 / (e0 + e1) > e0 / (e0 + e1)) ? 255 : 0;           // argmax over [Q0, Q1], ties -> label 0
+    if (q_out) q_out[(long)c * N + i] = q;
+}
+
+struct CrfLattice {
+    int* off; float* bary; unsigned long long* hkeys; int* hid; unsigned long long* pkeys; int* nb; float* norm; float* kn; int* M;
+    int cap, mmax;
+};
+
+struct CrfLayout {
+    size_t total = 0;
+    template <typename T> T* carve(char* base, size_t n) {
+        total = (total + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + total) : nullptr;
+        total += n * sizeof(T);
+        return p;
+    }
+};
+
+int crf_cap(long n) {
+    long c = 1024;
+    while (c < 2 * n) c <<= 1;
+    return (int)c;
+}
+
+// the same carving serves the size query (base == nullptr) and the launch
+void crf_carve(CrfLayout& L, char* base, long N, int C, CrfLattice (&lat)[2], float*& val0, float*& val1, float*& q1, float*& u, float*& fg,
+               float*& fb, int*& flags) {
+    const int dims[2] = {2, 5};
+    for (int k = 0; k < 2; ++k) {
+        const long nv = N * (dims[k] + 1);
+        lat[k].cap = crf_cap(nv);
+        lat[k].mmax = (int)nv;
+        lat[k].off = L.carve<int>(base, nv);
+        lat[k].bary = L.carve<float>(base, nv);
+        lat[k].hkeys = L.carve<unsigned long long>(base, lat[k].cap);
+        lat[k].hid = L.carve<int>(base, lat[k].cap);
+        lat[k].pkeys = L.carve<unsigned long long>(base, nv);
+        lat[k].nb = L.carve<int>(base, nv * (dims[k] + 1) * 2);
+        lat[k].norm = L.carve<float>(base, N);
+        lat[k].kn = L.carve<float>(base, N);
+    }
+    const long vmax = (N * 6 + 1) * (long)C;
+    val0 = L.carve<float>(base, vmax);
+    val1 = L.carve<float>(base, vmax);
+    q1 = L.carve<float>(base, N * C);
+    u = L.carve<float>(base, N * C * 2);
+    fg = L.carve<float>(base, N * C);
+    fb = L.carve<float>(base, N * C);
+    flags = L.carve<int>(base, 4);            // M of the two lattices, key overflow flag
+    lat[0].M = flags; lat[1].M = flags ? flags + 1 : nullptr;
+}
+
+template <int D>
+void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, int N,
+                int C, int sqrt_norm, hipStream_t s) {
+    const long vbytes = ((long)lt.mmax + 1) * C * sizeof(float);
+    (void)hipMemsetAsync(val0, 0, vbytes, s);
+    (void)hipMemsetAsync(val1, 0, (size_t)C * sizeof(float), s);                // row 0 of the ping-pong partner stays zero
+    hipLaunchKernelGGL(crf_splat_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, in, scale_in, lt.off, lt.bary, val0, N, C);
+    float* a = val0;
+    float* b = val1;
+    const long work = (long)lt.mmax * C;
+    for (int j = 0; j <= D; ++j) {
+        hipLaunchKernelGGL(crf_blur_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C);
+        float* t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm);
+}
+
+template <int D>
+void crf_build(const CrfLattice& lt, const unsigned char* rgb, int H, int W, float sxy, float srgb, int* overflow, float* val0, float* val1,
+               hipStream_t s) {
+    const int N = H * W;
+    const long nv = (long)N * (D + 1);
+    (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)lt.cap * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, rgb, H, W, 1.0f / sxy, 1.0f / srgb, lt.hkeys,
+                       (unsigned)(lt.cap - 1), lt.off, lt.bary, overflow);
+    hipLaunchKernelGGL(crf_assign_kernel, dim3((lt.cap + 255) / 256), dim3(256), 0, s, lt.hkeys, lt.cap, lt.hid, lt.pkeys, lt.M);
+    hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
+    hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.pkeys, lt.M, lt.hkeys, lt.hid,
+                       (unsigned)(lt.cap - 1), lt.nb, lt.mmax);
+    // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
+    crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, s);
+    crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, s);
+}
+
+}  // namespace
+
+extern "C" int64_t simseg_dense_crf_workspace_bytes(int64_t H, int64_t W, int64_t C) {
+    if (H <= 0 || W <= 0 || C <= 0 || C > CRF_MAXC) return -1;
+    CrfLayout L;
+    CrfLattice lat[2];
+    float *v0, *v1, *q1, *u, *fg, *fb;
+    int* flags;
+    crf_carve(L, nullptr, H * W, (int)C, lat, v0, v1, q1, u, fg, fb, flags);
+    return (int64_t)L.total + 256;
+}
+
+// rgb [H,W,3] uint8 (the de-normalised network input, RGB), prob [C,H,W] fp32 in [0,1] (min-max normalised candidate maps) ->
+// mask [C,H,W] uint8 (255 where the CRF labels the pixel as the class, else 0); q_out (optional) [C,H,W] = Q(label 1).
+extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t C, int64_t H, int64_t W, float sxy_g,
+                                float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+    SS_CHECK(rgb && prob && mask && workspace, "dense_crf: null pointer");
+    SS_CHECK(H > 0 && W > 0 && H * W < (1ll << 24), "dense_crf: image of %lld x %lld pixels is out of range", (long long)H, (long long)W);
+    SS_CHECK(C >= 1 && C <= CRF_MAXC, "dense_crf: 1..%d candidate maps per call (got %lld)", CRF_MAXC, (long long)C);
+    SS_CHECK(iters >= 1 && sxy_g > 0.f && sxy_b > 0.f && srgb > 0.f, "dense_crf: bad parameters");
+    SS_CHECK(((uintptr_t)workspace % 256) == 0, "dense_crf: workspace must be 256-byte aligned");
+    SS_CHECK(workspace_bytes >= simseg_dense_crf_workspace_bytes(H, W, C), "dense_crf: workspace too small (%lld < %lld bytes)",
+             (long long)workspace_bytes, (long long)simseg_dense_crf_workspace_bytes(H, W, C));
+    // lattice coordinates must fit the packed keys: |elevated| <~ (d + 1) * sqrt(2/3) * sum of feature ranges
+    SS_CHECK((float)(H > W ? H : W) / sxy_g * 3.0f < 30000.f && ((float)(H > W ? H : W) / sxy_b + 256.f / srgb) * 12.f < 2000.f,
+             "dense_crf: feature range too large for the packed lattice keys");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = (int)(H * W), Ci = (int)C;
+    CrfLayout L;
+    CrfLattice lat[2];
+    float *val0, *val1, *q1, *u, *fg, *fb;
+    int* flags;
+    crf_carve(L, static_cast<char*>(workspace), N, Ci, lat, val0, val1, q1, u, fg, fb, flags);
+    (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
+    crf_build<2>(lat[0], rgb, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
+    crf_build<5>(lat[1], rgb, (int)H, (int)W, sxy_b, srgb, flags + 2, val0, val1, s);
+    const long nc = (long)N * Ci;
+    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, N, Ci);
+    for (int it = 0; it < iters; ++it) {
+        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, s);
+        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, N, Ci, 0, s);
+        const bool last = it + 1 == iters;
+        hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
+                           q1, last ? mask : nullptr, last ? q_out : nullptr, N, Ci);
+    }
+    SS_LAUNCH_CHECK("dense_crf");
+    return 0;
+}

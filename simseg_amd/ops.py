@@ -339,3 +339,29 @@ def seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index=2
     call("simseg_seg_predict", ptr(_c(masks)), ptr(_c(cand_idx)), ptr(_c(cand_score)), ptr(_c(labels)), ptr(pred) if want_pred else None,
          ptr(hist), B, ncand, Hm, Wm, H, W, int(num_classes), int(ignore_index), stream())
     return pred, hist
+
+
+_CRF_WS = {}
+
+
+def dense_crf(rgb, prob, sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3, want_q=False):
+    """tools/seg_evaluation.py:31-54 for the C candidate maps of one image.  rgb [H,W,3] uint8 (RGB), prob [C,H,W] fp32 in [0,1]
+    -> (mask [C,H,W] uint8 0/255, Q(label 1) [C,H,W] fp32 or None)."""
+    require_gpu(rgb, prob)
+    if rgb.dtype != torch.uint8 or prob.dtype != torch.float32:
+        raise TypeError("dense_crf: rgb uint8 [H,W,3], prob fp32 [C,H,W]")
+    C, H, W = prob.shape
+    if tuple(rgb.shape) != (H, W, 3):
+        raise ValueError(f"dense_crf: image {tuple(rgb.shape)} does not match the {H}x{W} maps")
+    nbytes = raw("simseg_dense_crf_workspace_bytes", H, W, C)
+    if nbytes < 0:
+        raise ValueError(f"dense_crf: 1..8 candidate maps per call (got {C})")
+    key = (rgb.device, torch.cuda.current_stream().cuda_stream)
+    ws = _CRF_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _CRF_WS[key] = torch.empty(nbytes, device=rgb.device, dtype=torch.uint8)
+    mask = torch.empty(C, H, W, device=rgb.device, dtype=torch.uint8)
+    q = torch.empty(C, H, W, device=rgb.device, dtype=torch.float32) if want_q else None
+    call("simseg_dense_crf", ptr(_c(rgb)), ptr(_c(prob)), ptr(mask), ptr(q), C, H, W, float(sxy_g), float(compat_g), float(sxy_b), float(srgb),
+         float(compat_b), int(iters), ptr(ws), nbytes, stream())
+    return mask, q

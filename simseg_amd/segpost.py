@@ -5,27 +5,53 @@
     sim    = patch_text_similarity(model.image_projection(feats), text)      # [B, n*n, C]   (K14)
     out    = segment(sim, pooled @ text.T, labels, n, top_cls_num)
 
-The reference runs a CPU DenseCRF (pydensecrf, absent from this image) between the normalised map and the morphology; here
-the binary map is the CRF's unary decision (prob > 0.5).  A caller that has a CRF passes `refine`: it receives the
-probabilities [B,ncand,16n,16n] and the candidate table and returns uint8 masks of the same shape (0/255) - everything
-after it (7x7 dilate + erode, nearest resize, score-weighted argmax, IoU histograms) is the reference's arithmetic again.
+Between the normalised map and the morphology the reference runs a fully connected CRF on the CPU for every visited candidate
+(pydensecrf, :31-54 / :153).  Here it is `ops.dense_crf` - mean-field inference on two permutohedral lattices built on the device -
+when the caller hands over the de-normalised network inputs (`images_u8`, what the tool builds at :104); without them the binary
+map is the CRF's unary decision (prob > 0.5), and a caller-supplied `refine` hook can replace either.  Everything after it (7x7
+dilate + erode, nearest resize, score-weighted argmax, IoU histograms) is the reference's arithmetic again.
 """
 import torch
 
 from . import ops
 
 
+CRF_PARAMS = dict(sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3)        # tools/seg_evaluation.py:48-51
+
+
+def crf_masks(prob_up, cand_idx, images_u8, **params):
+    """prob_up [B,K,H,W] fp32 (x16 nearest-upsampled normalised maps), cand_idx [B,K] (-1 = slot not visited), images_u8 [B,H,W,3]
+    -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the reference loops on
+    the host per image and candidate); the lattices of an image are shared by its candidates."""
+    B, K, H, W = prob_up.shape
+    masks = torch.zeros(B, K, H, W, device=prob_up.device, dtype=torch.uint8)
+    visited = (cand_idx >= 0).cpu()
+    kw = dict(CRF_PARAMS, **params)
+    for b in range(B):
+        ks = visited[b].nonzero().flatten().tolist()
+        if not ks:
+            continue
+        m, _ = ops.dense_crf(images_u8[b].contiguous(), prob_up[b, ks].contiguous(), **kw)
+        masks[b, ks] = m
+    return masks
+
+
 def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand=5, ignore_index=255, refine=None, hist=None,
-            want_pred=True, closing=True):
-    """sim [B,n*n,C] fp32, scores [B,C], labels [B,H,W] uint8 -> dict(pred, hist, cand_idx, cand_score, threshold)."""
+            want_pred=True, closing=True, images_u8=None):
+    """sim [B,n*n,C] fp32, scores [B,C], labels [B,H,W] uint8 -> dict(pred, hist, cand_idx, cand_score, threshold).
+    images_u8 [B,16n,16n,3] uint8 (RGB): run the reference's DenseCRF on every visited candidate map."""
     C = sim.shape[2]
     num_classes = num_classes or C
     cand_idx, cand_score, thr = ops.seg_select(scores, top_cls_num, ncand)
-    masks, prob = ops.seg_masks(sim, cand_idx, num_patch, want_prob=refine is not None)
-    if refine is not None:
+    need_prob = refine is not None or images_u8 is not None
+    masks, prob = ops.seg_masks(sim, cand_idx, num_patch, want_prob=need_prob)
+    if need_prob:
         B, K, N = prob.shape
         up = prob.view(B, K, num_patch, num_patch).repeat_interleave(16, 2).repeat_interleave(16, 3)
-        masks = refine(up, cand_idx, cand_score).to(torch.uint8).contiguous()
+        if refine is not None:
+            masks = refine(up, cand_idx, cand_score).to(torch.uint8).contiguous()
+        else:
+            masks = crf_masks(up.contiguous(), cand_idx, images_u8)
     if closing:
         masks = ops.close7(masks, cand_idx.reshape(-1))                       # cv2.dilate then cv2.erode (:156-157), visited slots only
     pred, hist = ops.seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index, hist=hist, want_pred=want_pred)
