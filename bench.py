@@ -66,13 +66,19 @@ def synthetic_batch(B, img, L, vocab, seed, device):
     return {"image": image.to(device), "input_ids": ids.to(device), "attention_mask": mask.to(device)}
 
 
-def cpu_baseline(img, L, budget_s=20.0):
-    """The oracle (a torch fp32 restatement of the reference stack) doing the same training step on the host cores."""
-    from oracle import simseg_ref as R
-    # a bounded thread count: the GPU box reports 256 logical CPUs but oversubscribing them made round-1's first
-    # baseline run 100x slower than 8 threads in the build container
+def _cpu_threads():
+    # a bounded thread count: the GPU box reports 256 logical CPUs but oversubscribing them made round-1's first baseline run 100x
+    # slower than 8 threads in the build container
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    B = 2
+    return torch.get_num_threads()
+
+
+def cpu_baseline(img, L, budget_s=25.0):
+    """The oracle (a torch fp32 restatement of the reference stack) doing the same training step on the host cores: 8 pairs per
+    step (large enough to load the cores: 1.2 TFLOP per step)."""
+    from oracle import simseg_ref as R
+    threads = _cpu_threads()
+    B = 8
     ref = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=img), seed=2).train()
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
     b = synthetic_batch(B, img, L, 30522, 7, "cpu")
@@ -86,17 +92,80 @@ def cpu_baseline(img, L, budget_s=20.0):
     t_warm = time.perf_counter()
     step()
     t_warm = time.perf_counter() - t_warm
-    log(f"cpu_baseline: warm-up step of {B} pairs took {t_warm:.1f}s on {torch.get_num_threads()} threads")
+    log(f"cpu_baseline: warm-up step of {B} pairs took {t_warm:.1f}s on {threads} threads")
     n, t0 = 0, time.perf_counter()
     while n < 1 or (time.perf_counter() - t0 + t_warm < budget_s and n < 20):
         step()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(B * n / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{n} fwd+bwd+AdamW steps of {B} pairs (ViT-B/16 @{img}, BERT-base L={L}) with the torch-fp32 oracle"}
 
 
-def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768):
+def cpu_baseline_seg(img=512, classes=171, windows=1):
+    """The seg leg on the host cores, one window: oracle ViT-B tower -> projection -> pooled embedding + similarity map -> candidate
+    selection -> min-max map -> DenseCRF (numpy restatement of pydensecrf's inference) -> 7x7 dilate/erode -> resize -> argmax ->
+    IoU histograms, i.e. the reference's per-image loop (tools/seg_evaluation.py:99-170) with the oracle's pieces."""
+    import numpy as np
+    from oracle import crf_ref as CR
+    from oracle import segpost_ref as SR
+    from oracle import simseg_ref as R
+    threads = _cpu_threads()
+    n = img // 16
+    g = torch.Generator().manual_seed(3)
+    vit = R.init_weights_(R.RefViT("vit_base_patch16_224_in21k", img), seed=4).eval()
+    proj = torch.randn(512, 768, generator=g) * 0.02
+    text = torch.nn.functional.normalize(torch.randn(classes, 512, generator=g), dim=-1)
+    image = torch.randn(windows, 3, img, img, generator=g)
+    rgb = torch.randint(0, 256, (windows, img, img, 3), generator=g, dtype=torch.int64).numpy().astype(np.uint8)
+    labels = torch.randint(0, classes, (windows, img, img), generator=g)
+    t0 = time.perf_counter()
+    visited = 0
+    with torch.no_grad():
+        feats = vit(image)[:, 1:]
+        tok = feats @ proj.T
+        pooled = R.l2norm(R.topk_pool(tok, 5))
+        sim = R.seg_similarity(tok, text)
+        scores = pooled @ text.T
+    for b in range(windows):
+        idx, sc, thr = SR.select_candidates(scores[b], 10)
+        temp = np.zeros((classes, img, img))
+        for k, c in enumerate(idx):
+            if c < 0:
+                continue
+            visited += 1
+            norm, _ = SR.normalised_map(sim[b, :, c].numpy(), n)
+            m = (CR.dense_crf(rgb[b], norm) * 255).astype(np.uint8)
+            m = SR.morph7_fast(SR.morph7_fast(m, False), True)
+            temp[c] = m.astype(np.float64) * sc[k]
+        SR.intersect_and_union(torch.from_numpy(temp.argmax(0)), labels[b], classes)
+    dt = time.perf_counter() - t0
+    return {"value": round(windows / dt, 4), "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": f"{windows} window(s) of {img}x{img}, {classes} classes, {visited} candidate map(s) through the DenseCRF restatement (oracle ViT-B "
+                      f"tower + per-image loop of tools/seg_evaluation.py)"}
+
+
+def cpu_baseline_retrieval(m=1000, n=5000, d=512):
+    """The retrieval leg on the host cores at reduced size: the reference's argsort + gather + first-match path
+    (tasks/clip/hooks/utils.py:35-75) as restated in the oracle, both directions."""
+    from oracle import simseg_ref as R
+    threads = _cpu_threads()
+    g = torch.Generator().manual_seed(5)
+    img = torch.nn.functional.normalize(torch.randn(m, d, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(img.repeat_interleave(n // m, 0) + 0.08 * torch.randn(n, d, generator=g), dim=-1)
+    gi, gt = torch.arange(m), torch.arange(n) // (n // m)
+    R.retrieval_recalls(img, gi, txt, gt)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or time.perf_counter() - t0 < 5.0:
+        R.retrieval_recalls(img, gi, txt, gt)
+        R.retrieval_recalls(txt, gt, img, gi)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(2.0 * m * n / dt, 1), "unit": "similarities/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} evaluations of {m}x{n}x{d}, both directions (argsort + gather + first match, the reference's path)"}
+
+
+def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171, tag="vit_base_patch16_224_in21k", dim=768, crf=False):
     """Zero-shot segmentation GPU stage (BASELINE configs[3] shape): ViT-B on 512x512 windows -> projection -> LoDA pooled
     embedding + dense patch x class-text similarity map for all `classes` + candidate selection, masks, 7x7 morphology,
     resize/argmax and IoU histograms on the device (tools/seg_evaluation.py:99-170 without the CPU CRF stage).  Independent
@@ -116,6 +185,12 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     labels = torch.randint(0, classes, (windows, img, img), generator=g, dtype=torch.int64).to(torch.uint8)
     labels[torch.rand(windows, img, img, generator=g) < 0.05] = 255
     labels = labels.to(dev)
+    # de-normalised network inputs for the DenseCRF (tools/seg_evaluation.py:104): smooth colour fields + noise, so that the
+    # bilateral kernel has structure to follow
+    yy, xx = torch.meshgrid(torch.arange(img), torch.arange(img), indexing="ij")
+    base_rgb = torch.stack([(xx * 255 // img), (yy * 255 // img), ((xx + yy) * 127 // img)], -1).float()
+    images_u8 = (base_rgb[None] + 20 * torch.randn(min(windows, 8), img, img, 3, generator=g)).clamp(0, 255).to(torch.uint8)
+    images_u8 = images_u8.repeat((windows + 7) // 8, 1, 1, 1)[:windows].contiguous().to(dev)
     hist = torch.zeros(3, classes, device=dev, dtype=torch.int64)
     cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     from simseg_amd import segpost
@@ -130,7 +205,7 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
             scores = ops.gemm(pooled, text)                             # [B, classes]
             # post-processing of tools/seg_evaluation.py:112-170 on the device (the CPU DenseCRF is outside the path)
             post_ev[0].record()
-            out = segpost.segment(sim, scores, labels, img // 16, 10, hist=hist, want_pred=False)
+            out = segpost.segment(sim, scores, labels, img // 16, 10, hist=hist, want_pred=False, images_u8=images_u8 if crf else None)
             post_ev[1].record()
         return sim, scores, out
 
@@ -177,7 +252,8 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     return {"post_ms_per_step": round(post_ms, 3), "post_visited_candidates_per_window": round(visited / windows, 2),
             "post_GBps": round(post_bytes / post_ms / 1e6, 1),
             "post_frac_of_hbm_peak": round(post_bytes / post_ms / 1e6 / 8000.0, 4), "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
-            "classes": classes, "windows_per_batch": windows, "batches_in_flight": 2, "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
+            "classes": classes, "windows_per_batch": windows, "batches_in_flight": 2, "dense_crf": bool(crf),
+            "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
             "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
 
 
@@ -303,9 +379,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cpu = None
+    cpu = cpu_seg = cpu_retr = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.img, args.seq_len)
+        if not args.no_seg:
+            cpu_seg = cpu_baseline_seg()
+            log(f"cpu seg baseline: {cpu_seg}")
+            cpu_retr = cpu_baseline_retrieval()
+            log(f"cpu retrieval baseline: {cpu_retr}")
 
     log("cpu baseline done" if cpu else "no cpu baseline")
     from simseg.core import init_device
@@ -387,6 +468,9 @@ def main():
     seg = None
     if not args.no_seg:
         seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16"),
+               # the same stage with the reference's DenseCRF in (device mean field on permutohedral lattices, tools/seg_evaluation.py:153)
+               "fp32_crf": seg_eval_bench(dev, world, "fp32", crf=True, steps=1), "bf16_crf": seg_eval_bench(dev, world, "bf16", crf=True, steps=1),
+               "vit_s_288_fp32_crf": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
                # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
                "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
                "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
@@ -395,10 +479,14 @@ def main():
                                      seg_latency_bench(dev, "fp32", 512, 171, "vit_base_patch16_224_in21k", 768),
                                      seg_latency_bench(dev, "bf16", 512, 171, "vit_base_patch16_224_in21k", 768)]
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+        if cpu_seg is not None:
+            seg["cpu_baseline"] = cpu_seg
         log(f"seg eval stage: {seg}")
     retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
     if retr is not None:
         retr["encoder_inclusive"] = retrieval_encode_bench(dev)
+        if cpu_retr is not None:
+            retr["cpu_baseline"] = cpu_retr
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"retrieval eval: {retr}")
 
@@ -411,10 +499,14 @@ def main():
         cnt, fl, sec = agg[dom]
         achieved = fl / sec / 1e12
         gemm_sec = sum(a[2] for a in agg.values())
-        traffic = None          # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this command
+        # HBM bytes per launch of that kernel: from the rocprofv3 PMC passes of THIS command on THIS round's kernels (counters cannot be
+        # read from inside the process); the entry is used only if it was measured on the kernel variant that dominates now
+        traffic, traffic_src = None, None
         try:
-            with open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")) as f:
-                traffic = json.load(f)["per_kind"].get(dom, {}).get("hbm_bytes_per_launch")
+            with open(os.path.join(REPO, "profiles", "r2_pmc_traffic.json")) as f:
+                ent = json.load(f)["per_kind"].get(dom)
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], f"profiles/r2_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of {ent['kernel'][:60]}"
         except (OSError, ValueError, KeyError):
             pass
         kdesc = {"_P": "gemm_pp_kernel (256x256 tile, two wave groups in ping-pong, direct-to-LDS half-tile ring)",
@@ -433,7 +525,7 @@ def main():
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic,
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
                          "flops_per_launch_avg": fl / cnt,
                          "measured": "one instrumented step with both towers on one stream (each launch alone on the GPU); the timed "

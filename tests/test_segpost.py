@@ -33,6 +33,7 @@ def test_oracle_morph7_matches_scipy():
     for im in (img, grey):
         assert np.array_equal(SR.morph7(im, False), ndi.grey_dilation(im, size=(7, 7), mode="constant", cval=0))
         assert np.array_equal(SR.morph7(im, True), ndi.grey_erosion(im, size=(7, 7), mode="constant", cval=255))
+        assert np.array_equal(SR.morph7_fast(im, False), SR.morph7(im, False)) and np.array_equal(SR.morph7_fast(im, True), SR.morph7(im, True))
 
 
 def test_oracle_closing_is_identity_on_patch_maps():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""profiles/r1_pmc_fetch_size.txt + r1_pmc_write_size.txt (tools/pmc_stats.py output of the two rocprofv3 --pmc passes of
-bench.py) -> profiles/r1_pmc_traffic.json keyed by the GEMM kinds bench.py reports."""
+"""profiles/<round>_pmc_fetch_size.txt + <round>_pmc_write_size.txt (tools/pmc_stats.py output of the two rocprofv3 --pmc passes of
+bench.py) -> profiles/<round>_pmc_traffic.json keyed by the GEMM kinds bench.py reports."""
 import json
 import re
 import sys
@@ -18,17 +18,17 @@ def parse(path, counter):
 
 def kind_of(name):
     m = re.search(r"gemm_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)E", name)
-    large = False
+    suffix = ""
     if not m:
-        m2 = re.search(r"gemm_large_kernelI(DF16b|f)Lb(\d)ELb(\d)E", name)
+        m2 = re.search(r"gemm_(large|pp)_kernelI(DF16b|f)Lb(\d)ELb(\d)E", name)
         if not m2:
             return None
-        tin, tout, ta, tb, large = "DF16b", m2.group(1), m2.group(2), m2.group(3), True
+        tin, tout, ta, tb, suffix = "DF16b", m2.group(2), m2.group(3), m2.group(4), "_L" if m2.group(1) == "large" else "_P"
     else:
         tin, tout, ta, tb = m.groups()
     k = ("bf16" if tin == "DF16b" else "f32") + "_" + ("t" if ta == "1" else "n") + ("n" if tb == "1" else "t")
     k += "_o16" if tout == "DF16b" else "_o32"
-    return k + ("_L" if large else "")
+    return k + suffix
 
 
 def main(prefix="profiles/r1"):

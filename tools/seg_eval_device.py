@@ -7,9 +7,10 @@ how the work is laid out, not in what is computed:
   * images are processed `--batch` at a time and the similarity map is one fused kernel for all classes (reference: one
     image, up to five GEMVs with host syncs, :99-143);
   * candidate selection, min-max normalisation, binarisation, 7x7 dilate/erode, nearest resize, score-weighted argmax and
-    the IoU histograms run on the device (simseg_amd.segpost, :112-170).  The CPU DenseCRF between normalisation and
-    morphology is NOT run: the binary map is the CRF's unary decision.  With pydensecrf installed, `--crf` routes the
-    normalised maps through the reference's dense_crf settings on the host (:30-54) and returns to the device after it.
+    the IoU histograms run on the device (simseg_amd.segpost, :112-170), and so does the DenseCRF between normalisation and
+    morphology (:31-54 / :153: mean-field inference on two permutohedral lattices, simseg_dense_crf).  `--no-crf` stops at the
+    CRF's unary decision; with pydensecrf installed `--host-crf` routes the maps through the library on the host instead
+    (cross-check of the device CRF against the package the reference uses).
 
     python tools/seg_eval_device.py --cfg configs/clip/simseg.vit-b.yaml --ckpt_path ckpts/simseg.vit-b.pth
     python tools/seg_eval_device.py --cfg configs/clip/simseg.vit-s.yaml --synthetic 64        # no data / checkpoint needed
@@ -31,7 +32,8 @@ def parse_args():
     ap.add_argument("--ckpt_path", default="")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N synthetic images with random weights")
-    ap.add_argument("--crf", action="store_true", help="host DenseCRF refinement (needs pydensecrf)")
+    ap.add_argument("--no-crf", action="store_true", help="skip the DenseCRF (binary map = its unary decision)")
+    ap.add_argument("--host-crf", action="store_true", help="DenseCRF with pydensecrf on the host instead of the device kernels")
     return ap.parse_known_args()
 
 
@@ -147,11 +149,13 @@ def main():
                     feats = model.forward_image_feature(image)
                     pooled = model.forward_image_project(feats)
                     sim = patch_text_similarity(model.image_projection(feats), text)
-                    refine = None
-                    if args.crf:
-                        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
-                        refine = host_crf_refine(raw)
-                    segpost.segment(sim, ops.gemm(pooled, text), label, n, top_cls_num, hist=hist, want_pred=False, refine=refine)
+                    refine = raw = None
+                    if not args.no_crf:         # the de-normalised input the tool hands to dense_crf (tools/seg_evaluation.py:104)
+                        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+                        if args.host_crf:
+                            refine, raw = host_crf_refine(raw.cpu().numpy()), None
+                    segpost.segment(sim, ops.gemm(pooled, text), label, n, top_cls_num, hist=hist, want_pred=False, refine=refine,
+                                    images_u8=raw)
                 count += image.shape[0]
         for st in streams:
             cur.wait_stream(st)
