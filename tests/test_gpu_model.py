@@ -116,6 +116,8 @@ def test_vit_tower_vs_hf_golden(golden, monkeypatch):
 def test_train_step_ws1_vs_reference_golden(golden, monkeypatch):
     """forward(batch) -> loss -> backward, world size 1, against the reference's own loss/acc/gradients."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    from simseg_amd import towers
+    towers.SHADOW_HITS[0] = 0
     g = golden("clip_train_ws1")
     m = _build(golden)
     m.eval()          # the fixture was generated in eval mode (no dropout) so that gradients are comparable
@@ -126,7 +128,7 @@ def test_train_step_ws1_vs_reference_golden(golden, monkeypatch):
     assert abs(loss.item() - float(g["r0.loss"])) < 2e-2 * abs(float(g["r0.loss"]))
     assert abs(a1.item() - float(g["r0.i2t_acc"])) < 1e-6 and abs(a2.item() - float(g["r0.t2i_acc"])) < 1e-6
     from simseg_amd import towers
-    assert towers.SHADOW_HITS[0] > 0          # block-to-block bf16 gradient hand-off: the fast path is the one that ran
+    assert towers.SHADOW_HITS[0] >= 2         # final LN -> block 1 -> block 0 of the tiny ViT: the bf16 gradient hand-off is the path that ran
     params = dict(m.named_parameters())
     for k in g.files:
         if not k.startswith("r0.grad."):
