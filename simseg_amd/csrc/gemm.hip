@@ -769,7 +769,6 @@ int launch_large(const GemmParams& p, int splitk, hipStream_t stream) {
 //     registers: one A set (32) + two B sets (2 x 16) + 128 accumulators.
 // =================================================================================================================
 constexpr int PP_HALF = 128 * 64 * 2;
-constexpr int PP_LEAD = 4;
 constexpr int PP_BREG = 4 * PP_HALF;           // LDS: [A: tile parity x half][B: tile parity x half][dummy], 16 KiB each
 constexpr int PP_DUMMY = 8 * PP_HALF;
 
@@ -844,7 +843,10 @@ struct PPFrag {
     }
 };
 
-template <typename TO, bool TA, bool TB>
+// PP_LEAD: half-tiles in flight ahead of the phase that reads them (3..5; the ring of two K-tiles allows up to 6).  PRIO: 1 = raise the
+// wave priority around every MFMA cluster, 2 = static priority for the second group only, 0 = none.  Measured (tools/gemm_bench.py,
+// r2): LEAD 3 / 4 / 5 and PRIO 0 / 1 / 2 are all within run-to-run noise (+-2 %) on the training shapes and on 4096^3 / 8192^3.
+template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -906,14 +908,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #define PP_READ_B(FB, PAR, HALF) \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) FB[kk_] = frb.read(lds, ((PAR) * 2 + (HALF)) * PP_HALF, 0, kk_);
 #define PP_CLUSTER(RH, CH, FB)                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                   \
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                    \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) mma<bf16_t>(acc[2 * (RH) + i_][CH], fa[i_ * 4 + kk_], FB[kk_]); \
-    __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
 
     // ---- prologue: half-tiles 0..PP_LEAD on their way, 0 and 1 landed, B half 0 of the first K-tile in registers
-    PP_STAGE(0, 0) PP_STAGE(1, 1) PP_STAGE(2, 2) PP_STAGE(3, 3) PP_STAGE(4, 0)
-    wait_vm<2 * (PP_LEAD - 1)>();                                   // half-tiles 0 and 1: three younger ones may be in flight
+    PP_STAGE(0, 0) PP_STAGE(1, 1) PP_STAGE(2, 2) PP_STAGE(3, 3)
+    if (PP_LEAD >= 4) PP_STAGE(4, 0)
+    if (PP_LEAD >= 5) PP_STAGE(5, 1)
+    wait_vm<2 * (PP_LEAD - 1)>();                                   // half-tiles 0 and 1: the younger ones may be in flight
+    if (PRIO == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PP_READ_B(fb0, 0, 0)
@@ -973,11 +978,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     flush_colsum(p, cs, c0, c1, lane);
 }
 
-template <typename TO, bool TA, bool TB>
+template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1>
 int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
-    auto kern = gemm_pp_kernel<TO, TA, TB>;
+    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
