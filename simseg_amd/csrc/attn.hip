@@ -1083,6 +1083,312 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 backward, short sequences (T <= 256): "resident" forms of the two passes.  The streaming kernels above move one
+// 32-query (or 64-key) tile per iteration through LDS behind a register prefetch of ONE tile and a workgroup barrier: with ~600
+// cycles of MFMA work per iteration and 2-5 k cycles of global latency under load, every iteration waits for its tile (17 us per
+// block of 7 iterations at T = 197).  Here a block is one (batch, head); the operand that is walked - Q and dO for the dK/dV pass,
+// K and V for the dQ pass - is copied whole into LDS by global_load_lds once (rows padded to a multiple of 32 by repeating row
+// T-1: their lse = +inf / key bias = -inf makes every probability exactly 0), and each wave then runs over all tiles of it with no
+// barrier, no staging and no register prefetch in the loop.
+// One swizzle serves both ways these tiles are read (k-contiguous b128 fragments AND transposed ds_read_b64_tr_b16 fragments of
+// the same image): 16-byte slot c of row r holds chunk c ^ ((3 * (r >> 1)) & 7): a bijection over eight consecutive row pairs
+// (conflict-free b128 reads of 32 consecutive rows) whose neighbouring row pairs differ in more than bit 0 (the 4-row blocks of a
+// transposed read do not collide either).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int qd_swz(int r) { return (3 * (r >> 1)) & 7; }
+
+// copy `rows32` rows of 128 B (row stride `stride` elements, rows >= T repeat row T-1) into the swizzled LDS image at dst
+__device__ __forceinline__ void res_copy_rows(const bf16_t* src, long stride, int T, int rows32, char* dst, int wave, int nw, int lane) {
+    for (int piece = wave; piece < (rows32 >> 3); piece += nw) {
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ qd_swz(r);
+        const int rr = r < T ? r : T - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)rr * stride + c * 8),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 tr_frag2(const char* pa, const char* pb) {
+    union { struct { s16x4 lo, hi; } h; bf16x8 v; } u;
+    u.h.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa));
+    u.h.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
+    return u.v;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];      // [Q rows32 x 128][dO rows32 x 128][lse rows32][delta rows32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, kl = lane & 31;
+    const int bh_ = blockIdx.x;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int q32 = (T + 31) / 32, rows32 = q32 * 32;
+    char* ldsQ = lds;
+    char* ldsG = lds + rows32 * 128;
+    float* lse_l = reinterpret_cast<float*>(ldsG + rows32 * 128);
+    float* del_l = lse_l + rows32;
+    res_copy_rows(base, RS, T, rows32, ldsQ, wave, nw, lane);
+    res_copy_rows(gbase, OS, T, rows32, ldsG, wave, nw, lane);
+    for (int q = tid; q < rows32; q += nthr) {
+        lse_l[q] = q < T ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;            // -> P = 0 for padded queries
+        del_l[q] = q < T ? p.delta[((long)b * p.H + h) * T + q] : 0.f;
+    }
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const float scale = p.scale_log2e * 0.6931471805599453f;
+    // fragment addressing inside a 32-query tile (tile start rows are multiples of 32: the swizzle terms depend on the lane only)
+    const int arow = kl * 128, asw = qd_swz(kl);                                   // A operand rows = queries, 16-byte chunk 2 kk + h2
+    const int trow = (4 * h2 + (a16 >> 2)) * 128, tsw = qd_swz(4 * h2 + (a16 >> 2));
+    const int tch = g16 * 2 + ((a16 & 3) >> 1), tsub = ((a16 & 3) & 1) * 8;       // transposed: chunk db * 4 + tch, 8-byte half tsub
+    bool landed = false;
+
+#pragma unroll 1
+    for (int kt = wave; kt < q32; kt += nw) {
+        const int key = kt * 32 + kl;
+        const bool kvalid = key < T;
+        const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        bf16x8 kr[4], vr[4];     // this lane's K and V row chunks: B operands of S = Q.K^T and dP = dO.V^T
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { u32x4 v; bf16x8 hh; } uk, uv;
+            uk.v = (u32x4){0u, 0u, 0u, 0u}; uv.v = uk.v;
+            if (kvalid) {
+                uk.v = *reinterpret_cast<const u32x4*>(base + (long)key * RS + p.H * 64 + (2 * kk + h2) * 8);
+                uv.v = *reinterpret_cast<const u32x4*>(base + (long)key * RS + 2 * p.H * 64 + (2 * kk + h2) * 8);
+            }
+            kr[kk] = uk.hh; vr[kk] = uv.hh;
+        }
+        if (!landed) {                  // first pass: the LDS image is complete once every wave's copies have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            landed = true;
+        }
+        f32x16 dk[2], dv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+        for (int qt = 0; qt < q32; ++qt) {
+            const int q0 = qt * 32;
+            const char* cq = ldsQ + q0 * 128;
+            const char* cg = ldsG + q0 * 128;
+            bf16x8 aq[4], ag[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = arow + (((2 * kk + h2) ^ asw) << 4);
+                aq[kk] = ld_bf16x8(cq + off);
+                ag[kk] = ld_bf16x8(cg + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
+            }
+            // requested while the MFMAs run: lse / delta of this lane's 16 query rows, and the transposed dO / Q fragments
+            float4 l4[4], d4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                l4[j] = *reinterpret_cast<const float4*>(lse_l + q0 + 8 * j + 4 * h2);
+                d4[j] = *reinterpret_cast<const float4*>(del_l + q0 + 8 * j + 4 * h2);
+            }
+            bf16x8 gf[4], qf[4];                              // index s2 * 2 + db
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ro = (16 * (i >> 1)) * 128 + trow;
+                const int ca = ((((i & 1) * 4 + tch) ^ tsw) << 4) + tsub, cb = ((((i & 1) * 4 + tch) ^ tsw ^ 4) << 4) + tsub;
+                gf[i] = tr_frag2(cg + ro + ca, cg + ro + 8 * 128 + cb);      // dO^T fragment: [d][q-slots]
+                qf[i] = tr_frag2(cq + ro + ca, cq + ro + 8 * 128 + cb);      // Q^T fragment
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // lane: key column kl, rows q = (r%4) + 8*(r/4) + 4*h2
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float lq = reinterpret_cast<const float*>(&l4[r >> 2])[r & 3];
+                const float dq_ = reinterpret_cast<const float*>(&d4[r >> 2])[r & 3];
+                const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lq, 0.f));
+                float keep = 1.f;
+                if (DROP) {
+                    const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    const unsigned idx = ((unsigned)bh_ * T + (q0 + qq)) * T + key;
+                    keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                }
+                pd[r] = pr * keep;                                   // dropped probabilities feed dV
+                ds[r] = pr * (dp[r] * keep - dq_) * scale;          // dS feeds dK
+            }
+            // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)pd[8 * s2 + e]; df[e] = (bf16_t)ds[8 * s2 + e]; }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
+                }
+            }
+        }
+        // dk/dv accumulators (transposed): column = this lane's key, rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
+        if (kvalid) {
+            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)key * RS;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = db * 32 + 8 * r4 + 4 * h2;
+                    store_bf16x4(drow + p.H * 64 + d, dk[db][4 * r4], dk[db][4 * r4 + 1], dk[db][4 * r4 + 2], dk[db][4 * r4 + 3]);
+                    store_bf16x4(drow + 2 * p.H * 64 + d, dv[db][4 * r4], dv[db][4 * r4 + 1], dv[db][4 * r4 + 2], dv[db][4 * r4 + 3]);
+                }
+        }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];      // [K rows32 x 128][V rows32 x 128][key bias rows32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    const int bh_ = blockIdx.x;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int q32 = (T + 31) / 32, rows32 = q32 * 32;
+    char* ldsK = lds;
+    char* ldsV = lds + rows32 * 128;
+    float* kbias = reinterpret_cast<float*>(ldsV + rows32 * 128);
+    res_copy_rows(base + p.H * 64, RS, T, rows32, ldsK, wave, nw, lane);
+    res_copy_rows(base + 2 * p.H * 64, RS, T, rows32, ldsV, wave, nw, lane);
+    for (int key = tid; key < rows32; key += nthr)
+        kbias[key] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const float scale = p.scale_log2e * 0.6931471805599453f;
+    const int arow = ql * 128, asw = qd_swz(ql);
+    const int trow = (4 * h2 + (a16 >> 2)) * 128, tsw = qd_swz(4 * h2 + (a16 >> 2));
+    const int tch = g16 * 2 + ((a16 & 3) >> 1), tsub = ((a16 & 3) & 1) * 8;
+    bool landed = false;
+
+#pragma unroll 1
+    for (int qt = wave; qt < q32; qt += nw) {
+        const int q = qt * 32 + ql;
+        const bool qvalid = q < T;
+        bf16x8 qr[4], gr[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { u32x4 v; bf16x8 hh; } uq, ug;
+            uq.v = (u32x4){0u, 0u, 0u, 0u}; ug.v = uq.v;
+            if (qvalid) {
+                uq.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
+                ug.v = *reinterpret_cast<const u32x4*>(gbase + (long)q * OS + (2 * kk + h2) * 8);
+            }
+            qr[kk] = uq.hh; gr[kk] = ug.hh;
+        }
+        const float lse = qvalid ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;
+        const float del = qvalid ? p.delta[((long)b * p.H + h) * T + q] : 0.f;
+        if (!landed) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            landed = true;
+        }
+        f32x16 dq[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+        for (int kt = 0; kt < q32; ++kt) {
+            const int k0 = kt * 32;
+            const char* ck = ldsK + k0 * 128;
+            const char* cv = ldsV + k0 * 128;
+            // S^T[key][q], dP^T[key][q]: rows = keys (A from LDS), columns = queries (B = this lane's Q / dO row)
+            bf16x8 ak[4], av[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = arow + (((2 * kk + h2) ^ asw) << 4);
+                ak[kk] = ld_bf16x8(ck + off);
+                av[kk] = ld_bf16x8(cv + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[kk], qr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kk], gr[kk], dp, 0, 0, 0);
+            }
+            float4 b4[4];                                 // key bias of this lane's 16 key rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(kbias + k0 + 8 * j + 4 * h2);
+            bf16x8 kf[4];                                 // K^T fragments [d][key-slots], index s2 * 2 + db
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ro = (16 * (i >> 1)) * 128 + trow;
+                const int ca = ((((i & 1) * 4 + tch) ^ tsw) << 4) + tsub, cb = ((((i & 1) * 4 + tch) ^ tsw ^ 4) << 4) + tsub;
+                kf[i] = tr_frag2(ck + ro + ca, ck + ro + 8 * 128 + cb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float kbv = reinterpret_cast<const float*>(&b4[r >> 2])[r & 3];
+                const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kbv - lse, 0.f));
+                float keep = 1.f;
+                if (DROP) {
+                    const int kk_ = k0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    const unsigned idx = ((unsigned)bh_ * T + q) * T + kk_;
+                    keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                }
+                ds[r] = pr * (dp[r] * keep - del) * scale;
+            }
+            // dQ^T[d][q] += K^T[d][keys] . dS^T[keys][q]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 df;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) df[e] = (bf16_t)ds[8 * s2 + e];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
+            }
+        }
+        if (qvalid) {
+            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)q * RS;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    store_bf16x4(drow + db * 32 + 8 * r4 + 4 * h2, dq[db][4 * r4], dq[db][4 * r4 + 1], dq[db][4 * r4 + 2], dq[db][4 * r4 + 3]);
+        }
+    }
+}
+
+template <bool DROP>
+int launch_bwd_res(const AttnParams& p, hipStream_t stream) {
+    const int q32 = (p.T + 31) / 32, rows32 = q32 * 32;
+    const int smem = 2 * rows32 * 128 + 2 * rows32 * 4;
+    static bool configured = false;
+    if (!configured) {
+        const int mx = 2 * RES_MAXT * 128 + 2 * RES_MAXT * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_res_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_res_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if (e != hipSuccess) return simseg_set_error("attention_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const dim3 grid((unsigned)(p.B * p.H)), block((q32 < 4 ? q32 : 4) * 64);
+    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<DROP>, grid, block, smem, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DROP>, grid, block, smem, stream, p);
+    return 0;
+}
+
 // Waves (= 32-query tiles) per block.  The kernels hold 2-3 waves per SIMD (register bound), i.e. 8-12 waves per CU, which
 // 4-wave blocks tile exactly.  Measured on ViT-B (profiles/r1_kernel_roofline.txt): 4-wave blocks win at T = 197 (7 row tiles,
 // one padded slot) AND at T = 1025 (33 row tiles: 0.109 ms against 0.136 ms for 3-wave blocks without padding and 0.164 ms
@@ -1181,7 +1487,9 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
-    if (p.drop_thresh) {
+    if (T <= RES_MAXT && g_attn_variant != 1) {
+        if (int rc = p.drop_thresh ? launch_bwd_res<true>(p, s) : launch_bwd_res<false>(p, s)) return rc;
+    } else if (p.drop_thresh) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(nw * 64), 0, s, p);
     } else {
