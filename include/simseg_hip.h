@@ -188,11 +188,12 @@ int simseg_seg_predict(const void* masks, const int* cand_idx, const float* cand
 /* The fully connected CRF the reference applies to every visited candidate map (tools/seg_evaluation.py:31-54, called at :153:
  * pydensecrf DenseCRF2D with 2 labels, U = -log([1-p, p] + 1e-8), addPairwiseGaussian(sxy=3, compat=3), addPairwiseBilateral(sxy=40,
  * srgb=13, rgbim, compat=10), inference(3), argmax), as mean-field inference on two permutohedral lattices built on the device.
- * rgb [H,W,3] bytes (the de-normalised network input, RGB order), prob [C,H,W] fp32 in [0,1] (C <= 8 candidate maps of ONE image:
- * the lattices are shared) -> mask [C,H,W] bytes (255 where the pixel is labelled as the class); q_out (optional) [C,H,W] fp32 =
- * Q(label 1) after the last iteration.  workspace: caller-allocated, 256-byte aligned, simseg_dense_crf_workspace_bytes(H, W, C). */
-int64_t simseg_dense_crf_workspace_bytes(int64_t H, int64_t W, int64_t C);
-int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t C, int64_t H, int64_t W, float sxy_g,
+ * rgb [B,H,W,3] bytes (the de-normalised network inputs, RGB order), prob [B,C,H,W] fp32 in [0,1] (C <= 8 candidate maps per image:
+ * an image's maps share its lattices; the images of a batch are independent problems solved side by side in the same launches) ->
+ * mask [B,C,H,W] bytes (255 where the pixel is labelled as the class); q_out (optional) [B,C,H,W] fp32 = Q(label 1) after the last
+ * iteration.  workspace: caller-allocated, 256-byte aligned, simseg_dense_crf_workspace_bytes(B, H, W, C). */
+int64_t simseg_dense_crf_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
+int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t B, int64_t C, int64_t H, int64_t W, float sxy_g,
                      float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace, int64_t workspace_bytes,
                      void* stream);
 

@@ -23,21 +23,24 @@ namespace {
 constexpr unsigned long long CRF_EMPTY = ~0ull;
 constexpr int CRF_MAXC = 8;
 
-template <int D> struct KeyBits { static constexpr int B = D <= 2 ? 16 : 12; };
+// 64-bit lattice keys: D coordinates of B bits each (offset binary) and, above them, the index of the image in the batch - the
+// lattices of the images of a batch live side by side in ONE hash table / point list and never share a point.
+template <int D> struct KeyBits { static constexpr int B = D <= 2 ? 16 : 10; static constexpr int IMG_BITS = 64 - D * B > 14 ? 14 : 64 - D * B; };
 
 template <int D>
-__device__ __forceinline__ unsigned long long crf_pack(const int (&k)[D]) {
+__device__ __forceinline__ unsigned long long crf_pack(const int (&k)[D], int img) {
     constexpr int B = KeyBits<D>::B;
-    unsigned long long key = 0;
+    unsigned long long key = (unsigned long long)img << (D * B);
 #pragma unroll
     for (int i = 0; i < D; ++i) key |= (unsigned long long)((unsigned)(k[i] + (1 << (B - 1))) & ((1u << B) - 1)) << (i * B);
     return key;
 }
 template <int D>
-__device__ __forceinline__ void crf_unpack(unsigned long long key, int (&k)[D]) {
+__device__ __forceinline__ int crf_unpack(unsigned long long key, int (&k)[D]) {
     constexpr int B = KeyBits<D>::B;
 #pragma unroll
     for (int i = 0; i < D; ++i) k[i] = (int)((key >> (i * B)) & ((1u << B) - 1)) - (1 << (B - 1));
+    return (int)(key >> (D * B));
 }
 __device__ __forceinline__ unsigned crf_hash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
@@ -63,14 +66,15 @@ __device__ __forceinline__ int crf_find(const unsigned long long* hkeys, const i
 
 // Permutohedral::init, one thread per pixel (pixel i = y * W + x).  D = 2: (x, y) / sxy;  D = 5: (x, y) / sxy, rgb / srgb.
 template <int D>
-__global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int H, int W, float inv_sxy, float inv_srgb,
+__global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int nimg, int H, int W, float inv_sxy, float inv_srgb,
                                                           unsigned long long* __restrict__ hkeys, unsigned mask, int* __restrict__ off,
                                                           float* __restrict__ bary, int* __restrict__ overflow) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= H * W) return;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // pixel of the batch: image i / (H W)
+    if (i >= (long)nimg * H * W) return;
+    const int img = (int)(i / (H * W)), li = (int)(i % (H * W));
     float f[D];
-    f[0] = (float)(i % W) * inv_sxy;
-    f[1] = (float)(i / W) * inv_sxy;
+    f[0] = (float)(li % W) * inv_sxy;
+    f[1] = (float)(li / W) * inv_sxy;
     if constexpr (D == 5) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) f[2 + c] = (float)rgb[(long)i * 3 + c] * inv_srgb;
@@ -135,15 +139,15 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
             key[k] = (int)rintf(rem0[k]) + (rank[k] <= D - r ? r : r - (D + 1));        // canonical simplex, remainder r
             bad = bad || key[k] < -(1 << (KeyBits<D>::B - 1)) || key[k] >= (1 << (KeyBits<D>::B - 1));
         }
-        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key));       // hash slot for now; dense id after crf_assign
+        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key, img));  // hash slot for now; dense id after crf_assign
         bary[(long)i * (D + 1) + r] = bc[r];
     }
     if (bad) atomicExch(overflow, 1);
 }
 
-__global__ __launch_bounds__(256) void crf_assign_kernel(const unsigned long long* __restrict__ hkeys, int cap, int* __restrict__ hid,
+__global__ __launch_bounds__(256) void crf_assign_kernel(const unsigned long long* __restrict__ hkeys, long cap, int* __restrict__ hid,
                                                          unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
     if (s >= cap) return;
     const unsigned long long k = hkeys[s];
     if (k == CRF_EMPTY) return;
@@ -160,27 +164,27 @@ __global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off,
 template <int D>
 __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long long* __restrict__ pkeys, const int* __restrict__ M,
                                                             const unsigned long long* __restrict__ hkeys, const int* __restrict__ hid,
-                                                            unsigned mask, int* __restrict__ nb, int mmax) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= *M) return;
-    int key[D];
-    crf_unpack<D>(pkeys[i], key);
+                                                            unsigned mask, int* __restrict__ nb, long mmax) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < *M; i += (long)gridDim.x * 256) {
+        int key[D];
+        const int img = crf_unpack<D>(pkeys[i], key);
 #pragma unroll
-    for (int j = 0; j <= D; ++j) {
-        int k1[D], k2[D];
+        for (int j = 0; j <= D; ++j) {
+            int k1[D], k2[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { k1[k] = key[k] - 1; k2[k] = key[k] + 1; }
-        if (j < D) { k1[j] = key[j] + D; k2[j] = key[j] - D; }
-        nb[((long)j * mmax + i) * 2 + 0] = crf_find(hkeys, hid, mask, crf_pack<D>(k1));
-        nb[((long)j * mmax + i) * 2 + 1] = crf_find(hkeys, hid, mask, crf_pack<D>(k2));
+            for (int k = 0; k < D; ++k) { k1[k] = key[k] - 1; k2[k] = key[k] + 1; }
+            if (j < D) { k1[j] = key[j] + D; k2[j] = key[j] - D; }
+            nb[((long)j * mmax + i) * 2 + 0] = crf_find(hkeys, hid, mask, crf_pack<D>(k1, img));
+            nb[((long)j * mmax + i) * 2 + 1] = crf_find(hkeys, hid, mask, crf_pack<D>(k2, img));
+        }
     }
 }
 
 // splat: val[(off + 1) * C + c] += bary * scale_i * in[i * C + c]   (in == nullptr: the constant 1, one channel)
 template <int D>
 __global__ __launch_bounds__(256) void crf_splat_kernel(const float* __restrict__ in, const float* __restrict__ scale, const int* __restrict__ off,
-                                                        const float* __restrict__ bary, float* __restrict__ val, int N, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                        const float* __restrict__ bary, float* __restrict__ val, long N, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     float v[CRF_MAXC];
     const float sc = scale ? scale[i] : 1.0f;
@@ -195,19 +199,20 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ nbj,
                                                        const int* __restrict__ M, int C) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    const long i = t / C;
-    const int c = (int)(t % C);
-    if (i >= *M) return;
-    const int n1 = nbj[i * 2] + 1, n2 = nbj[i * 2 + 1] + 1;                  // -1 -> row 0 (zeros)
-    dst[(i + 1) * C + c] = src[(i + 1) * C + c] + 0.5f * (src[(long)n1 * C + c] + src[(long)n2 * C + c]);
+    const long total = (long)*M * C;                              // (the launch is sized for a typical lattice, not the worst case)
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / C;
+        const int c = (int)(t % C);
+        const int n1 = nbj[i * 2] + 1, n2 = nbj[i * 2 + 1] + 1;              // -1 -> row 0 (zeros)
+        dst[(i + 1) * C + c] = src[(i + 1) * C + c] + 0.5f * (src[(long)n1 * C + c] + src[(long)n2 * C + c]);
+    }
 }
 
 // slice: out[i * C + c] = scale_i * alpha * sum_r bary * val[(off + 1) * C + c]
 template <int D>
 __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ val, const float* __restrict__ scale, const int* __restrict__ off,
-                                                        const float* __restrict__ bary, float* __restrict__ out, int N, int C, int sqrt_norm) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                        const float* __restrict__ bary, float* __restrict__ out, long N, int C, int sqrt_norm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
     float acc[CRF_MAXC];
@@ -227,12 +232,13 @@ __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict_
 }
 
 // U = -log([1 - p, p] + 1e-8);  Q = softmax(-U)   (prob [C][N] -> q1 [N][C], u [N][C][2])
-__global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__ prob, float* __restrict__ q1, float* __restrict__ u, int N, int C) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)N * C) return;
+__global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__ prob, float* __restrict__ q1, float* __restrict__ u, long NT, int N,
+                                                       int C) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;          // NT = images x N pixels of the batch; prob is [image][C][N]
+    if (t >= NT * C) return;
     const long i = t / C;
     const int c = (int)(t % C);
-    const float p = prob[(long)c * N + i];
+    const float p = prob[((i / N) * C + c) * N + i % N];
     const float u0 = -logf((1.0f - p) + 1e-8f), u1 = -logf(p + 1e-8f);
     u[t * 2] = u0; u[t * 2 + 1] = u1;
     const float t0 = -u0, t1 = -u1, mx = fmaxf(t0, t1);
@@ -244,9 +250,9 @@ __global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict__ u, const float* __restrict__ fg, const float* __restrict__ fb,
                                                          const float* __restrict__ kng, const float* __restrict__ knb, float wg, float wb,
                                                          float* __restrict__ q1, unsigned char* __restrict__ mask, float* __restrict__ q_out,
-                                                         int N, int C) {
+                                                         long NT, int N, int C) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)N * C) return;
+    if (t >= NT * C) return;
     const long i = t / C;
     const int c = (int)(t % C);
     const float g1 = fg[t], b1 = fb[t];
@@ -256,13 +262,14 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict
     const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
     const float q = e1 / (e0 + e1);
     q1[t] = q;
-    if (mask) mask[(long)c * N + i] = (e1 / (e0 + e1) > e0 / (e0 + e1)) ? 255 : 0;           // argmax over [Q0, Q1], ties -> label 0
-    if (q_out) q_out[(long)c * N + i] = q;
+    const long o = ((i / N) * C + c) * N + i % N;
+    if (mask) mask[o] = (e1 / (e0 + e1) > e0 / (e0 + e1)) ? 255 : 0;                          // argmax over [Q0, Q1], ties -> label 0
+    if (q_out) q_out[o] = q;
 }
 
 struct CrfLattice {
     int* off; float* bary; unsigned long long* hkeys; int* hid; unsigned long long* pkeys; int* nb; float* norm; float* kn; int* M;
-    int cap, mmax;
+    long cap, mmax;
 };
 
 struct CrfLayout {
@@ -275,10 +282,10 @@ struct CrfLayout {
     }
 };
 
-int crf_cap(long n) {
+long crf_cap(long n) {
     long c = 1024;
     while (c < 2 * n) c <<= 1;
-    return (int)c;
+    return c;
 }
 
 // the same carving serves the size query (base == nullptr) and the launch
@@ -288,7 +295,7 @@ void crf_carve(CrfLayout& L, char* base, long N, int C, CrfLattice (&lat)[2], fl
     for (int k = 0; k < 2; ++k) {
         const long nv = N * (dims[k] + 1);
         lat[k].cap = crf_cap(nv);
-        lat[k].mmax = (int)nv;
+        lat[k].mmax = nv;
         lat[k].off = L.carve<int>(base, nv);
         lat[k].bary = L.carve<float>(base, nv);
         lat[k].hkeys = L.carve<unsigned long long>(base, lat[k].cap);
@@ -309,85 +316,109 @@ void crf_carve(CrfLayout& L, char* base, long N, int C, CrfLattice (&lat)[2], fl
     lat[0].M = flags; lat[1].M = flags ? flags + 1 : nullptr;
 }
 
-template <int D>
-void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, int N,
-                int C, int sqrt_norm, hipStream_t s) {
-    const long vbytes = ((long)lt.mmax + 1) * C * sizeof(float);
-    (void)hipMemsetAsync(val0, 0, vbytes, s);
-    (void)hipMemsetAsync(val1, 0, (size_t)C * sizeof(float), s);                // row 0 of the ping-pong partner stays zero
-    hipLaunchKernelGGL(crf_splat_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, in, scale_in, lt.off, lt.bary, val0, N, C);
-    float* a = val0;
-    float* b = val1;
-    const long work = (long)lt.mmax * C;
-    for (int j = 0; j <= D; ++j) {
-        hipLaunchKernelGGL(crf_blur_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C);
-        float* t = a; a = b; b = t;
-    }
-    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm);
+unsigned crf_blocks(long work) {
+    long b = (work + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
 template <int D>
-void crf_build(const CrfLattice& lt, const unsigned char* rgb, int H, int W, float sxy, float srgb, int* overflow, float* val0, float* val1,
+void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, long N,
+                int C, int sqrt_norm, hipStream_t s) {
+    const long vbytes = (lt.mmax + 1) * C * sizeof(float);
+    (void)hipMemsetAsync(val0, 0, vbytes, s);
+    (void)hipMemsetAsync(val1, 0, (size_t)C * sizeof(float), s);                // row 0 of the ping-pong partner stays zero
+    hipLaunchKernelGGL(crf_splat_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, scale_in, lt.off, lt.bary, val0, N, C);
+    float* a = val0;
+    float* b = val1;
+    for (int j = 0; j <= D; ++j) {
+        // lattice points are a fraction of the worst case N (D + 1): a grid-stride launch sized for N / 4 points per channel
+        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * C)), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C);
+        float* t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm);
+}
+
+template <int D>
+void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, int W, float sxy, float srgb, int* overflow, float* val0, float* val1,
                hipStream_t s) {
-    const int N = H * W;
-    const long nv = (long)N * (D + 1);
+    const long N = (long)nimg * H * W;
+    const long nv = N * (D + 1);
     (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)lt.cap * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, s, rgb, H, W, 1.0f / sxy, 1.0f / srgb, lt.hkeys,
+    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, 1.0f / sxy, 1.0f / srgb, lt.hkeys,
                        (unsigned)(lt.cap - 1), lt.off, lt.bary, overflow);
-    hipLaunchKernelGGL(crf_assign_kernel, dim3((lt.cap + 255) / 256), dim3(256), 0, s, lt.hkeys, lt.cap, lt.hid, lt.pkeys, lt.M);
+    hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((lt.cap + 255) / 256)), dim3(256), 0, s, lt.hkeys, lt.cap, lt.hid, lt.pkeys, lt.M);
     hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
-    hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.pkeys, lt.M, lt.hkeys, lt.hid,
+    hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, lt.hkeys, lt.hid,
                        (unsigned)(lt.cap - 1), lt.nb, lt.mmax);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
     crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, s);
     crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, s);
 }
 
+// largest |lattice coordinate| the features can produce: |elevated_j| <= sum_i cf_i + j cf_j, cf_i = fmax_i * scale_i (Permutohedral::init)
+float crf_key_bound(int D, const float* fmax) {
+    const float inv_std_dev = sqrtf(2.0f / 3.0f) * (D + 1);
+    float sum = 0.f, mx = 0.f;
+    for (int i = 0; i < D; ++i) {
+        const float cf = fmax[i] * inv_std_dev / sqrtf((float)((i + 1) * (i + 2)));
+        sum += cf;
+        mx = cf > mx ? cf : mx;
+    }
+    return sum + D * mx + 2 * (D + 1);
+}
+
 }  // namespace
 
-extern "C" int64_t simseg_dense_crf_workspace_bytes(int64_t H, int64_t W, int64_t C) {
-    if (H <= 0 || W <= 0 || C <= 0 || C > CRF_MAXC) return -1;
+extern "C" int64_t simseg_dense_crf_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C > CRF_MAXC) return -1;
     CrfLayout L;
     CrfLattice lat[2];
     float *v0, *v1, *q1, *u, *fg, *fb;
     int* flags;
-    crf_carve(L, nullptr, H * W, (int)C, lat, v0, v1, q1, u, fg, fb, flags);
+    crf_carve(L, nullptr, B * H * W, (int)C, lat, v0, v1, q1, u, fg, fb, flags);
     return (int64_t)L.total + 256;
 }
 
-// rgb [H,W,3] uint8 (the de-normalised network input, RGB), prob [C,H,W] fp32 in [0,1] (min-max normalised candidate maps) ->
-// mask [C,H,W] uint8 (255 where the CRF labels the pixel as the class, else 0); q_out (optional) [C,H,W] = Q(label 1).
-extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t C, int64_t H, int64_t W, float sxy_g,
-                                float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace, int64_t workspace_bytes,
-                                void* stream) {
+// rgb [B,H,W,3] uint8 (the de-normalised network inputs, RGB), prob [B,C,H,W] fp32 in [0,1] (min-max normalised candidate maps; the C
+// maps of an image share its lattices) -> mask [B,C,H,W] uint8 (255 where the CRF labels the pixel as the class, else 0); q_out
+// (optional) [B,C,H,W] = Q(label 1).  The images of a batch are independent problems solved side by side in the same launches.
+extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t B, int64_t C, int64_t H, int64_t W,
+                                float sxy_g, float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     SS_CHECK(rgb && prob && mask && workspace, "dense_crf: null pointer");
-    SS_CHECK(H > 0 && W > 0 && H * W < (1ll << 24), "dense_crf: image of %lld x %lld pixels is out of range", (long long)H, (long long)W);
-    SS_CHECK(C >= 1 && C <= CRF_MAXC, "dense_crf: 1..%d candidate maps per call (got %lld)", CRF_MAXC, (long long)C);
+    SS_CHECK(B >= 1 && B < (1 << 14), "dense_crf: 1..16383 images per call (got %lld)", (long long)B);
+    SS_CHECK(H > 0 && W > 0 && B * H * W < (1ll << 26), "dense_crf: batch of %lld images of %lld x %lld pixels is out of range", (long long)B,
+             (long long)H, (long long)W);
+    SS_CHECK(C >= 1 && C <= CRF_MAXC, "dense_crf: 1..%d candidate maps per image (got %lld)", CRF_MAXC, (long long)C);
     SS_CHECK(iters >= 1 && sxy_g > 0.f && sxy_b > 0.f && srgb > 0.f, "dense_crf: bad parameters");
     SS_CHECK(((uintptr_t)workspace % 256) == 0, "dense_crf: workspace must be 256-byte aligned");
-    SS_CHECK(workspace_bytes >= simseg_dense_crf_workspace_bytes(H, W, C), "dense_crf: workspace too small (%lld < %lld bytes)",
-             (long long)workspace_bytes, (long long)simseg_dense_crf_workspace_bytes(H, W, C));
-    // lattice coordinates must fit the packed keys: |elevated| <~ (d + 1) * sqrt(2/3) * sum of feature ranges
-    SS_CHECK((float)(H > W ? H : W) / sxy_g * 3.0f < 30000.f && ((float)(H > W ? H : W) / sxy_b + 256.f / srgb) * 12.f < 2000.f,
-             "dense_crf: feature range too large for the packed lattice keys");
+    SS_CHECK(workspace_bytes >= simseg_dense_crf_workspace_bytes(B, H, W, C), "dense_crf: workspace too small (%lld < %lld bytes)",
+             (long long)workspace_bytes, (long long)simseg_dense_crf_workspace_bytes(B, H, W, C));
+    {   // lattice coordinates must fit the packed keys
+        const float ext = (float)(H > W ? H : W);
+        const float f2[2] = {ext / sxy_g, ext / sxy_g}, f5[5] = {ext / sxy_b, ext / sxy_b, 255.f / srgb, 255.f / srgb, 255.f / srgb};
+        SS_CHECK(crf_key_bound(2, f2) < (float)(1 << 15) && crf_key_bound(5, f5) < (float)(1 << 9),
+                 "dense_crf: feature range too large for the packed lattice keys (%g, %g)", crf_key_bound(2, f2), crf_key_bound(5, f5));
+    }
     hipStream_t s = (hipStream_t)stream;
+    const long NT = B * H * W;
     const int N = (int)(H * W), Ci = (int)C;
     CrfLayout L;
     CrfLattice lat[2];
     float *val0, *val1, *q1, *u, *fg, *fb;
     int* flags;
-    crf_carve(L, static_cast<char*>(workspace), N, Ci, lat, val0, val1, q1, u, fg, fb, flags);
+    crf_carve(L, static_cast<char*>(workspace), NT, Ci, lat, val0, val1, q1, u, fg, fb, flags);
     (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
-    crf_build<2>(lat[0], rgb, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
-    crf_build<5>(lat[1], rgb, (int)H, (int)W, sxy_b, srgb, flags + 2, val0, val1, s);
-    const long nc = (long)N * Ci;
-    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, N, Ci);
+    crf_build<2>(lat[0], rgb, (int)B, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
+    crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, sxy_b, srgb, flags + 2, val0, val1, s);
+    const long nc = NT * Ci;
+    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci);
     for (int it = 0; it < iters; ++it) {
-        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, s);
-        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, N, Ci, 0, s);
+        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, NT, Ci, 0, s);
+        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, s);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
-                           q1, last ? mask : nullptr, last ? q_out : nullptr, N, Ci);
+                           q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci);
     }
     SS_LAUNCH_CHECK("dense_crf");
     return 0;

@@ -345,23 +345,29 @@ _CRF_WS = {}
 
 
 def dense_crf(rgb, prob, sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3, want_q=False):
-    """tools/seg_evaluation.py:31-54 for the C candidate maps of one image.  rgb [H,W,3] uint8 (RGB), prob [C,H,W] fp32 in [0,1]
-    -> (mask [C,H,W] uint8 0/255, Q(label 1) [C,H,W] fp32 or None)."""
+    """tools/seg_evaluation.py:31-54 for the C candidate maps of each image of a batch.  rgb [B,H,W,3] (or [H,W,3]) uint8 (RGB), prob
+    [B,C,H,W] (or [C,H,W]) fp32 in [0,1] -> (mask uint8 0/255, Q(label 1) fp32 or None), shaped like prob."""
     require_gpu(rgb, prob)
     if rgb.dtype != torch.uint8 or prob.dtype != torch.float32:
-        raise TypeError("dense_crf: rgb uint8 [H,W,3], prob fp32 [C,H,W]")
-    C, H, W = prob.shape
-    if tuple(rgb.shape) != (H, W, 3):
-        raise ValueError(f"dense_crf: image {tuple(rgb.shape)} does not match the {H}x{W} maps")
-    nbytes = raw("simseg_dense_crf_workspace_bytes", H, W, C)
+        raise TypeError("dense_crf: rgb uint8 [B,H,W,3], prob fp32 [B,C,H,W]")
+    single = prob.dim() == 3
+    if single:
+        rgb, prob = rgb[None], prob[None]
+    B, C, H, W = prob.shape
+    if tuple(rgb.shape) != (B, H, W, 3):
+        raise ValueError(f"dense_crf: images {tuple(rgb.shape)} do not match the maps {tuple(prob.shape)}")
+    nbytes = raw("simseg_dense_crf_workspace_bytes", B, H, W, C)
     if nbytes < 0:
-        raise ValueError(f"dense_crf: 1..8 candidate maps per call (got {C})")
+        raise ValueError(f"dense_crf: 1..8 candidate maps per image (got {C})")
     key = (rgb.device, torch.cuda.current_stream().cuda_stream)
     ws = _CRF_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        _CRF_WS.pop(key, None)
         ws = _CRF_WS[key] = torch.empty(nbytes, device=rgb.device, dtype=torch.uint8)
-    mask = torch.empty(C, H, W, device=rgb.device, dtype=torch.uint8)
-    q = torch.empty(C, H, W, device=rgb.device, dtype=torch.float32) if want_q else None
-    call("simseg_dense_crf", ptr(_c(rgb)), ptr(_c(prob)), ptr(mask), ptr(q), C, H, W, float(sxy_g), float(compat_g), float(sxy_b), float(srgb),
+    mask = torch.empty(B, C, H, W, device=rgb.device, dtype=torch.uint8)
+    q = torch.empty(B, C, H, W, device=rgb.device, dtype=torch.float32) if want_q else None
+    call("simseg_dense_crf", ptr(_c(rgb)), ptr(_c(prob)), ptr(mask), ptr(q), B, C, H, W, float(sxy_g), float(compat_g), float(sxy_b), float(srgb),
          float(compat_b), int(iters), ptr(ws), nbytes, stream())
+    if single:
+        return mask[0], (q[0] if want_q else None)
     return mask, q

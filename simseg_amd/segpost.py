@@ -19,20 +19,27 @@ from . import ops
 CRF_PARAMS = dict(sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3)        # tools/seg_evaluation.py:48-51
 
 
-def crf_masks(prob_up, cand_idx, images_u8, **params):
+def crf_masks(prob_up, cand_idx, images_u8, chunk=16, **params):
     """prob_up [B,K,H,W] fp32 (x16 nearest-upsampled normalised maps), cand_idx [B,K] (-1 = slot not visited), images_u8 [B,H,W,3]
     -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the reference loops on
-    the host per image and candidate); the lattices of an image are shared by its candidates."""
+    the host per image and candidate); images with a visited candidate go through the device CRF `chunk` at a time (the lattices of
+    an image are shared by its candidates; images that visit fewer candidates than the chunk's widest carry idle zero maps)."""
     B, K, H, W = prob_up.shape
     masks = torch.zeros(B, K, H, W, device=prob_up.device, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
-    for b in range(B):
-        ks = visited[b].nonzero().flatten().tolist()
-        if not ks:
-            continue
-        m, _ = ops.dense_crf(images_u8[b].contiguous(), prob_up[b, ks].contiguous(), **kw)
-        masks[b, ks] = m
+    todo = [(b, visited[b].nonzero().flatten().tolist()) for b in range(B)]
+    todo = [(b, ks) for b, ks in todo if ks]
+    for s in range(0, len(todo), chunk):
+        part = todo[s:s + chunk]
+        cmax = max(len(ks) for _, ks in part)
+        bs = [b for b, _ in part]
+        prob = torch.zeros(len(part), cmax, H, W, device=prob_up.device, dtype=torch.float32)
+        for j, (b, ks) in enumerate(part):
+            prob[j, :len(ks)] = prob_up[b, ks]
+        m, _ = ops.dense_crf(images_u8[bs].contiguous(), prob, **kw)
+        for j, (b, ks) in enumerate(part):
+            masks[b, ks] = m[j, :len(ks)]
     return masks
 
 

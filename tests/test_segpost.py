@@ -276,6 +276,27 @@ def test_dense_crf_kernels_vs_oracle(H, W, cell, C):
 
 
 @pytest.mark.gpu
+def test_dense_crf_batch_equals_per_image_calls():
+    """The images of a batch are solved side by side in ONE set of lattices (the image index is part of the lattice key): every
+    image's result equals its own single-image call, and the oracle."""
+    from oracle import crf_ref as CR
+    from simseg_amd import ops
+    H = W = 160
+    scenes = [_crf_scene(H, W, s, 16) for s in (3, 4, 5)]
+    scenes[1] = (scenes[1][0][::-1].copy(), scenes[1][1][::-1].copy(), scenes[1][2][::-1].copy())        # a different image content
+    imgs = torch.from_numpy(np.stack([s[0] for s in scenes])).cuda()
+    probs = torch.from_numpy(np.stack([np.stack([s[1], 1.0 - s[1]]) for s in scenes]).astype(np.float32)).cuda()
+    mask, q = ops.dense_crf(imgs, probs, want_q=True)
+    for b in range(3):
+        m1, q1 = ops.dense_crf(imgs[b], probs[b], want_q=True)
+        assert ((mask[b] > 0) == (m1 > 0)).float().mean() >= 0.9999
+        assert float((q[b] - q1).abs().max()) < 1e-3
+        for c in range(2):
+            want = CR.dense_crf(scenes[b][0], probs[b, c].cpu().numpy())
+            assert ((mask[b, c].cpu().numpy() > 0) == (want > 0)).mean() >= 0.999, (b, c)
+
+
+@pytest.mark.gpu
 def test_segment_with_crf_matches_per_image_oracle_loop():
     """segment(..., images_u8=...) == the reference's per-image loop (tools/seg_evaluation.py:128-163) with the oracle CRF: candidate
     selection, normalised x16 map, DenseCRF, 7x7 dilate + erode, nearest resize, score-weighted argmax."""
