@@ -23,13 +23,13 @@ def crf_masks(prob_up, cand_idx, images_u8, chunk=16, **params):
     """prob_up [B,K,H,W] fp32 (x16 nearest-upsampled normalised maps), cand_idx [B,K] (-1 = slot not visited), images_u8 [B,H,W,3]
     -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the reference loops on
     the host per image and candidate); images with a visited candidate go through the device CRF `chunk` at a time (the lattices of
-    an image are shared by its candidates; images that visit fewer candidates than the chunk's widest carry idle zero maps)."""
+    an image are shared by its candidates; images are grouped by their number of visited candidates)."""
     B, K, H, W = prob_up.shape
     masks = torch.zeros(B, K, H, W, device=prob_up.device, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
     todo = [(b, visited[b].nonzero().flatten().tolist()) for b in range(B)]
-    todo = [(b, ks) for b, ks in todo if ks]
+    todo = sorted(((b, ks) for b, ks in todo if ks), key=lambda t: len(t[1]))      # chunks of equal width: no idle zero maps
     for s in range(0, len(todo), chunk):
         part = todo[s:s + chunk]
         cmax = max(len(ks) for _, ks in part)
