@@ -403,9 +403,9 @@ def main():
     sync = None
     dp = os.environ.get("SIMSEG_BENCH_DP", "ddp")      # "ddp": torch DDP (bucketed all-reduce overlapped with backward, towers on one
     if world > 1:                                       # stream); "flat": simseg_amd.parallel.GradSync (one all-reduce, two-stream towers)
-        if dp == "flat":
+        if dp in ("flat", "bucket"):       # this package's exchange: keeps the two-stream towers; "bucket" overlaps it with the backward
             from simseg_amd.parallel import GradSync
-            sync = GradSync(model.parameters())
+            sync = GradSync(model.parameters(), overlap=(dp == "bucket"))
             os.environ.setdefault("SIMSEG_AMD_TWO_STREAMS", "1")
         else:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
@@ -520,7 +520,7 @@ def main():
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
-                       "gradient_sync": ("none" if world == 1 else ("flat all-reduce (simseg_amd.parallel.GradSync)" if sync is not None else "torch DDP")),
+                       "gradient_sync": ("none" if world == 1 else (f"simseg_amd.parallel.GradSync ({dp})" if sync is not None else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",

@@ -10,6 +10,9 @@
  *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); nothing synchronises;
  *   - return 0 on success, negative on error; the message is in simseg_last_error() (thread-local);
  *   - dtype codes: 0 = fp32, 1 = bf16.  Matrices are row-major.
+ *   - the compute entry points are stateless and re-entrant: everything a call needs is in its arguments.  The only library state
+ *     is per THREAD (thread_local): the last error string and the test / benchmark selectors `simseg_set_gemm_variant`,
+ *     `simseg_set_attention_variant` (default 0 = auto), which affect only later calls made by the thread that set them.
  */
 #ifndef SIMSEG_HIP_H
 #define SIMSEG_HIP_H
@@ -45,7 +48,7 @@ int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int
 int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M, int64_t C, int64_t K, int dtype, float eps,
                           int normalize, void* stream);
 
-/* Kernel selection for benchmarking / tests: 0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring kernel,
+/* Kernel selection for benchmarking / tests (thread-local; production callers never call it): 0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring kernel,
  * 3 = 256x256 ping-pong kernel (+100: debug, epilogue skipped and a cycle-counter timeline written to C by
  * tools/dbg_gemm_timeline.py). */
 int simseg_set_gemm_variant(int v);
@@ -96,7 +99,7 @@ int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 
-/* Kernel selection for benchmarking / tests: 0 auto (bf16 sequences of <= 128 tokens run the "resident" forward kernel that holds a
+/* Kernel selection for benchmarking / tests (thread-local): 0 auto (bf16 sequences of <= 128 tokens run the "resident" forward kernel that holds a
  * whole head's K / V in LDS), 1 = always the streaming ring kernel, 4 = resident for every T <= 256 (2 / 3: timing ablations). */
 int simseg_set_attention_variant(int v);
 int simseg_debug_attn_occupancy(int64_t T);

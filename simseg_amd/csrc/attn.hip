@@ -1395,7 +1395,7 @@ int launch_bwd_res(const AttnParams& p, hipStream_t stream) {
 // for 6-wave blocks) - fewer waves per barrier and per staged K/V tile beat a perfectly filled last block.
 int attn_waves_per_block(int q32) { return q32 <= 4 ? q32 : 4; }
 
-int g_attn_variant = 0;          // tests / benchmarks: 1 = always the streaming (ring) kernels
+thread_local int g_attn_variant = 0;   // tests / benchmarks (thread-local selector): 1 = always the streaming (ring) kernels
 
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
                 uint64_t seed, float drop_p) {

@@ -51,6 +51,7 @@ struct GemmParams {
     int row_group;           // >0: output row r -> (r / G) * (G + 1) + 1 + r % G  (ViT token rows after [cls])
     int res_mod;             // residual row = 1 + r % G (pos_embed) instead of the output row
     int accumulate;          // C += result (fp32 output only; always set when split-K)
+    int dbg_skip_epilogue;   // benchmarking only (simseg_set_gemm_variant(100 + v)): the accumulators are kept live but nothing is stored
     int ksplit;              // k-tiles per split-K slice
     int nsplit;              // number of split-K slices (grid = tiles * nsplit, slice-major so a slice's tiles share an XCD)
     // dropout on (acc*alpha + bias), before the residual:  keep iff hash(seed, row*N+col) >= thresh
@@ -189,7 +190,7 @@ template <typename TO>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16& accL, const f32x16& accR, float* wlds, int row0,
                                                int col0, int col1, int lane, bool atomic, bool vec_ok, float (&cs)[8]) {
     const int h2 = lane >> 5, cl = lane & 31;
-    if (p.accumulate == -1) {          // debug: epilogue skipped (keeps the accumulators live), for fixed-cost attribution
+    if (p.dbg_skip_epilogue) {         // debug: epilogue skipped (keeps the accumulators live), for fixed-cost attribution
         if (accL[0] + accR[0] == 12345.678f) static_cast<TO*>(p.C)[0] = (TO)1.f;
         return;
     }
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, MINW) void gemm_large_kernel(GemmPa
         if (FN > 2) flush_colsum(p, csb, cb, cb + 32, lane);
     }
     if (FN == 2) flush_colsum(p, cs, n0 + wn * 64, n0 + wn * 64 + 32, lane);
-    if (p.accumulate == -1 && blockIdx.x == 0 && tid == 0) {     // debug timeline (cycle counter) of block 0 / wave 0
+    if (p.dbg_skip_epilogue && blockIdx.x == 0 && tid == 0) {    // debug timeline (cycle counter) of block 0 / wave 0
         unsigned long long* d = reinterpret_cast<unsigned long long*>(p.C);
         d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t2 - dbg_t1; d[2] = dbg_t3 - dbg_t2; d[3] = __builtin_readcyclecounter() - dbg_t3;
     }
@@ -1002,7 +1003,9 @@ int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
 }
 
 
-int g_gemm_debug_skip_epilogue = 0;
+// Debug / benchmarking selectors.  Thread-local: the entry points are otherwise stateless and re-entrant, and a selector set by a
+// benchmark thread never changes what another caller's simseg_gemm launches.
+thread_local int g_gemm_debug_skip_epilogue = 0;
 thread_local int g_gemm_last_variant = 0;      // 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS, 3 = 256x256 ping-pong
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
@@ -1013,8 +1016,7 @@ thread_local int g_gemm_last_variant = 0;      // 1 = 128x128 register-staged, 2
 // spills, correct, but 556 vs 673 TFLOP/s aggregate with compiler scheduling at one wave per SIMD), 256x128 tiles on four 128x64 waves at two
 // blocks per CU so that one block's epilogue overlaps the other's K loop (launch_large<..., 32, 2|3, 256, 128, 2, 2, 2>: 630 vs 670), delaying the first round's blocks by 1/4..3/4 of a tile so the CUs' store bursts do not coincide (-1..-6 %), deeper BK32 rings (4 and 5 stages) and a
 // two-group ping-pong schedule of the 256x256 kernel (MFMA phase of one wave per SIMD against the load phase of the other).
-int g_gemm_variant = 0;
-int g_gemm_wgrad_large = 1;      // measured: 804 vs 660 TFLOP/s aggregate on the five wgrad shapes of the step (variant 7 turns it off)
+thread_local int g_gemm_variant = 0;
 
 template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
@@ -1104,7 +1106,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.A = A; p.B = B; p.C = C; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.bias = bias; p.rowscale = rowscale;
     p.residual = residual; p.ldr = ldr; p.act = act; p.aux = aux; p.aux_out = aux_out;
-    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = g_gemm_debug_skip_epilogue ? -1 : accumulate;
+    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = accumulate; p.dbg_skip_epilogue = g_gemm_debug_skip_epilogue;
     p.drop_seed = drop_seed;
     p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;

@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/simseg_hip.h).  PyTorch supplies device memory and the stream;
 all arithmetic runs in libsimseg_hip.so.  No autograd here (see autograd.py) and no CPU fallback."""
+import threading
+
 import torch
 
 from .lib import call, ptr, require_gpu, stream, raw
@@ -21,14 +23,29 @@ def _c(t):
     return t
 
 
+# The library's kernel selectors are thread-local (include/simseg_hip.h: the compute entry points are re-entrant), and autograd runs
+# backward on its own threads: the selection made here is kept in Python and pushed to whichever thread launches next.
+_VARIANT = {"gemm": 0, "attention": 0}
+_PUSHED = threading.local()
+
+
+def _push_variant(kind):
+    want = _VARIANT[kind]
+    if getattr(_PUSHED, kind, 0) != want:
+        call(f"simseg_set_{kind}_variant", want)
+        setattr(_PUSHED, kind, want)
+
+
 def set_gemm_variant(v):
     """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring, 3 = 256x256 ping-pong (tests / benchmarks only)."""
-    call("simseg_set_gemm_variant", int(v))
+    _VARIANT["gemm"] = int(v)
+    _push_variant("gemm")
 
 
 def set_attention_variant(v):
     """0 auto (bf16 sequences of <= 256 tokens on the resident kernels), 1 = always the streaming ring kernels (tests / benchmarks only)."""
-    call("simseg_set_attention_variant", int(v))
+    _VARIANT["attention"] = int(v)
+    _push_variant("attention")
 
 
 PROFILE = None   # bench.py sets this to a list to time every GEMM launch with events on the launch stream
@@ -50,6 +67,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         out = torch.empty(rows, N, device=a.device, dtype=out_dtype or a.dtype)
     _c(out)
     ldr = residual.shape[-1] if residual is not None else 0
+    _push_variant("gemm")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -161,6 +179,7 @@ def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=
         raise ValueError("attention: qkv last dim must be 3*heads*64")
     out = torch.empty(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
+    _push_variant("attention")
     call("simseg_attention_fwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(out), ptr(lse), dt(qkv), B, T, heads, float(scale),
          int(drop_seed), float(drop_p), stream())
     return out, lse
@@ -170,6 +189,7 @@ def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=
     B, T, W = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    _push_variant("attention")
     call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(delta), ptr(dqkv),
          B, T, heads, float(scale), int(drop_seed), float(drop_p), stream())
     return dqkv

@@ -73,6 +73,17 @@ def _worker(rank, world, port, q):
     sync()
     res["gsync"] = ([g_.tolist() for g_ in local], [p.grad.tolist() for p in lin.parameters() if p.requires_grad],
                     all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views)))
+    # the same exchange without overlap (one flat all-reduce after the backward) and with two small buckets: identical means
+    for kw in (dict(overlap=False), dict(overlap=True, bucket_mb=0)):
+        lin2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+        lin2.load_state_dict(lin.state_dict())
+        s2 = GradSync(lin2.parameters(), **kw)
+        for _ in range(2):                                   # second step: gradients dropped and re-delivered through the hooks
+            for p_ in lin2.parameters():
+                p_.grad = None
+            lin2(x).square().sum().backward()
+            s2.finish()
+        res.setdefault("gsync_alt", []).append([p.grad.tolist() for p in lin2.parameters()])
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -103,6 +114,12 @@ def test_gather_layer_matches_reference_two_ranks(world):
         assert o["blist"] == [1, 8]
         assert o["bobj"] == [{"rank": 0}, "x"]
         assert o["gsync"][2]
+    for r in range(world):                                       # flat / multi-bucket variants agree with the default
+        for alt in out[r]["gsync_alt"]:
+            ref = [g_ for g_ in out[r]["gsync"][1]]
+            got = [a for a, p_ok in zip(alt, [True, True, True, False]) if p_ok]
+            for a, b in zip(got, ref):
+                np.testing.assert_allclose(np.array(a), np.array(b), rtol=1e-6, atol=1e-7)
     for k in range(len(out[0]["gsync"][0])):                     # every rank ends with the mean of the two ranks' local gradients
         mean = (np.array(out[0]["gsync"][0][k]) + np.array(out[1]["gsync"][0][k])) / 2
         for r in range(world):
