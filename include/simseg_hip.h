@@ -107,14 +107,15 @@ int simseg_debug_attn_occupancy(int64_t T);
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]
  * (log2 domain, optional) is saved for the backward.  dtype 0 = exact fp32 MFMA, 1 = bf16 MFMA.  drop_p > 0 applies
- * HF attention_probs dropout (bf16 only).  Replaces timm Attention.forward (q@k^T*scale, softmax, @v) and HF
+ * HF attention_probs dropout.  Replaces timm Attention.forward (q@k^T*scale, softmax, @v) and HF
  * BertSelfAttention.forward as reached through vit_builder.py:18 / huggingface_builder.py:16-17. */
 int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B, int64_t T,
                          int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream);
-/* bf16 backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse; delta[B,H,T] is caller-provided fp32 scratch. */
+/* Backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse, all in `dtype` (0 = fp32: the exact mode of a non-AMP run,
+ * simseg/core/hooks/optimizer.py:76-77; 1 = bf16); delta[B,H,T] is caller-provided fp32 scratch. */
 int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
-                         float* delta, void* dqkv, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
-                         float drop_p, void* stream);
+                         float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
+                         uint64_t drop_seed, float drop_p, void* stream);
 
 /* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).
  * tools/seg_evaluation.py:71-73 (class_embeddings.mean(dim=0); /= norm()). */

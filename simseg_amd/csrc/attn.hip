@@ -218,6 +218,16 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(AttnParams p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        if (p.drop_thresh) {      // HF attention_probs dropout (same element index and hash as the bf16 kernels)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    const unsigned idx = ((unsigned)bh_ * T + q) * T + key;
+                    s[kb][r] = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
+                }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kv0 + kb * 32 >= T) continue;
@@ -244,6 +254,156 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(AttnParams p) {
                 *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * r4] * inv, o[db][4 * r4 + 1] * inv, o[db][4 * r4 + 2] * inv, o[db][4 * r4 + 3] * inv);
             }
         if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 backward (exact mode).  The reference trains in fp32 whenever cfg.dist.fp16 is off (simseg/core/config.py:50,
+// simseg/core/hooks/optimizer.py:76-77); this is also the arithmetic the hand-written bf16 backward is checked against.
+// One kernel body, two roles, same MFMA layout as attn_fwd_f32_kernel (lane column = an "own" row kept in registers, the
+// other side streamed through LDS 64 rows at a time):
+//   DKV = false: own = 32 queries (Q, dO in registers), streamed = keys (K, V):   dQ = scale * dS . K     (+ writes delta)
+//   DKV = true : own = 32 keys (K, V in registers), streamed = queries (Q, dO):   dK = scale * dS^T . Q,  dV = Pd^T . dO
+// with P = exp2(s * scale * log2e + keybias - lse), Pd = dropout(P), dS = P o (dropout(dO . V^T) - delta), delta = rowsum(dO o O).
+// ------------------------------------------------------------------------------------------------
+template <bool DKV, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * KT * KP32 + 2 * KT * 4];
+    char* lds1 = lds;                    // K (dQ role) / Q (dK,dV role)
+    char* lds2 = lds + KT * KP32;        // V            / dO
+    float* rowa = reinterpret_cast<float*>(lds + 2 * KT * KP32);     // key bias / lse of the streamed queries
+    float* rowb = rowa + KT;                                         //          / delta of the streamed queries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    int qb_, bh_;
+    if (!attn_block_map(p, qb_, bh_)) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = p.T;
+    const long HD = (long)p.H * 64, RS = 3 * HD;
+    const float* base = static_cast<const float*>(p.qkv) + (long)b * T * RS + h * 64;
+    const float* dob = static_cast<const float*>(p.dout) + (long)b * T * HD + h * 64;
+    const float* ob = static_cast<const float*>(p.out) + (long)b * T * HD + h * 64;
+    const long stat = ((long)b * p.H + h) * T;
+    const int nthr = blockDim.x;
+    const int own = qb_ * (nthr >> 1) + wave * 32 + ql;
+    const float c_ = p.scale_log2e, scale = p.scale_log2e * 0.6931471805599453f;
+
+    float a[8][4], g[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+        if (own < T) {
+            const int d = 8 * c + 4 * h2;
+            u = *reinterpret_cast<const float4*>(base + (long)own * RS + (DKV ? HD : 0) + d);
+            v = DKV ? *reinterpret_cast<const float4*>(base + (long)own * RS + 2 * HD + d)
+                    : *reinterpret_cast<const float4*>(dob + (long)own * HD + d);
+        }
+        a[c][0] = u.x; a[c][1] = u.y; a[c][2] = u.z; a[c][3] = u.w;
+        g[c][0] = v.x; g[c][1] = v.y; g[c][2] = v.z; g[c][3] = v.w;
+    }
+    float lse_own = 1e30f, delta_own = 0.f, bias_own = NEG;
+    if (!DKV) {
+        float dl = 0.f;
+        if (own < T) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 o4 = *reinterpret_cast<const float4*>(ob + (long)own * HD + 8 * c + 4 * h2);
+                dl += o4.x * g[c][0] + o4.y * g[c][1] + o4.z * g[c][2] + o4.w * g[c][3];
+            }
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        delta_own = dl;
+        if (own < T) {
+            lse_own = p.lse[stat + own];
+            if (h2 == 0) const_cast<float*>(p.delta)[stat + own] = dl;
+        }
+    } else if (own < T && (!p.mask || p.mask[(long)b * T + own] != 0)) bias_own = 0.f;
+
+    f32x16 acc1[2], acc2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; acc2[i][r] = 0.f; }
+
+    for (int j0 = 0; j0 < T; j0 += KT) {
+        __syncthreads();
+        for (int idx = tid; idx < KT * 16; idx += nthr) {
+            const int row = idx >> 4, c = idx & 15;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+            if (j0 + row < T) {
+                const float* rp = base + (long)(j0 + row) * RS + c * 4;
+                if (DKV) { x = *reinterpret_cast<const float4*>(rp); y = *reinterpret_cast<const float4*>(dob + (long)(j0 + row) * HD + c * 4); }
+                else { x = *reinterpret_cast<const float4*>(rp + HD); y = *reinterpret_cast<const float4*>(rp + 2 * HD); }
+            }
+            *reinterpret_cast<float4*>(lds1 + row * KP32 + c * 16) = x;
+            *reinterpret_cast<float4*>(lds2 + row * KP32 + c * 16) = y;
+        }
+        if (tid < KT) {
+            const int r = j0 + tid;
+            if (DKV) { rowa[tid] = r < T ? p.lse[stat + r] : 1e30f; rowb[tid] = r < T ? p.delta[stat + r] : 0.f; }
+            else rowa[tid] = (r < T && (!p.mask || p.mask[(long)b * T + r] != 0)) ? 0.f : NEG;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            if (j0 + jb * 32 >= T) continue;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 x = *reinterpret_cast<const float4*>(lds1 + (jb * 32 + ql) * KP32 + (8 * c + 4 * h2) * 4);
+                const float4 y = *reinterpret_cast<const float4*>(lds2 + (jb * 32 + ql) * KP32 + (8 * c + 4 * h2) * 4);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, a[c][0], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, g[c][0], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, a[c][1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, g[c][1], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, a[c][2], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, g[c][2], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, a[c][3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, g[c][3], dp, 0, 0, 0);
+            }
+            // s <- dS * scale, dp <- dropout(P)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                float pr, dl;
+                if (DKV) { pr = exp2f(fmaf(s[r], c_, bias_own) - rowa[row]); dl = rowb[row]; }
+                else { pr = exp2f(fmaf(s[r], c_, rowa[row]) - lse_own); dl = delta_own; }
+                float keep = 1.f;
+                if (DROP) {
+                    const unsigned qi = DKV ? j0 + row : own, ki = DKV ? own : j0 + row;
+                    const unsigned idx = ((unsigned)bh_ * T + qi) * T + ki;                 // < 2^32: checked by the host
+                    keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                }
+                s[r] = pr * (dp[r] * keep - dl) * scale;
+                dp[r] = pr * keep;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const float x = *reinterpret_cast<const float*>(lds1 + row * KP32 + (db * 32 + ql) * 4);
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, s[r], acc1[db], 0, 0, 0);
+                    if (DKV) {
+                        const float y = *reinterpret_cast<const float*>(lds2 + row * KP32 + (db * 32 + ql) * 4);
+                        acc2[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(y, dp[r], acc2[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (own < T) {
+        float* dst = static_cast<float*>(p.dqkv) + ((long)b * T + own) * RS + h * 64 + (DKV ? HD : 0);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                *reinterpret_cast<float4*>(dst + d) = make_float4(acc1[db][4 * r4], acc1[db][4 * r4 + 1], acc1[db][4 * r4 + 2], acc1[db][4 * r4 + 3]);
+                if (DKV)
+                    *reinterpret_cast<float4*>(dst + HD + d) = make_float4(acc2[db][4 * r4], acc2[db][4 * r4 + 1], acc2[db][4 * r4 + 2], acc2[db][4 * r4 + 3]);
+            }
     }
 }
 
@@ -1435,7 +1595,6 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
     SS_CHECK(out, "attention_fwd: null out");
-    SS_CHECK(dtype == 1 || drop_p == 0.f, "attention_fwd: dropout is a training (bf16) feature");
     SS_CHECK(dtype == 0 || !(key_mask || drop_p > 0.f) || T <= MAXT_BIAS, "attention_fwd: masked bf16 sequences are limited to %d keys", MAXT_BIAS);
     p.out = out; p.lse = lse;
     // one wave per 32 queries; a block holds up to 8 waves of the same (batch, head) so K/V tiles are staged once
@@ -1472,15 +1631,32 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
     return 0;
 }
 
-// bf16 backward: dqkv[B,T,3,H,64] from qkv, ctx (forward output), dctx, lse; delta[B,H,T] is caller-provided scratch.
+// backward: dqkv[B,T,3,H,64] from qkv, ctx (forward output), dctx, lse; delta[B,H,T] is caller-provided scratch.  All tensors in
+// `dtype` (0 = fp32 exact mode, 1 = bf16).
 extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
-                                    float* delta, void* dqkv, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
-                                    float drop_p, void* stream) {
+                                    float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
+                                    uint64_t drop_seed, float drop_p, void* stream) {
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
     SS_CHECK(out && dout && lse && delta && dqkv, "attention_bwd: null pointer");
+    SS_CHECK(dtype == 0 || dtype == 1, "attention_bwd: dtype must be 0 (fp32) or 1 (bf16)");
     p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta; p.dqkv = dqkv;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0) {
+        SS_CHECK(((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dqkv % 16) == 0, "attention_bwd: operands must be 16-byte aligned");
+        const int q32 = (int)((T + 31) / 32);
+        const int nw = attn_waves_per_block(q32);
+        dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
+        if (p.drop_thresh) {
+            hipLaunchKernelGGL((attn_bwd_f32_kernel<false, true>), grid, dim3(nw * 64), 0, s, p);       // dQ, writes delta
+            hipLaunchKernelGGL((attn_bwd_f32_kernel<true, true>), grid, dim3(nw * 64), 0, s, p);        // dK, dV
+        } else {
+            hipLaunchKernelGGL((attn_bwd_f32_kernel<false, false>), grid, dim3(nw * 64), 0, s, p);
+            hipLaunchKernelGGL((attn_bwd_f32_kernel<true, false>), grid, dim3(nw * 64), 0, s, p);
+        }
+        SS_LAUNCH_CHECK("attention_bwd (fp32)");
+        return 0;
+    }
     const long groups = B * T * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                        (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);

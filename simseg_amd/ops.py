@@ -191,7 +191,7 @@ def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=
     delta = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
     _push_variant("attention")
     call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(delta), ptr(dqkv),
-         B, T, heads, float(scale), int(drop_seed), float(drop_p), stream())
+         dt(qkv), B, T, heads, float(scale), int(drop_seed), float(drop_p), stream())
     return dqkv
 
 

@@ -1,5 +1,6 @@
-"""Encoder towers on the HIP kernels: ViT (timm semantics) and BERT (HF semantics), forward in exact-fp32 or bf16,
-backward in bf16 (fp32 accumulate, fp32 master weights/gradients, fp32 residual stream).
+"""Encoder towers on the HIP kernels: ViT (timm semantics) and BERT (HF semantics), forward and backward in exact fp32 (the
+reference without AMP: simseg/core/config.py:50, simseg/core/hooks/optimizer.py:76-77) or bf16 (fp32 accumulate, fp32 master
+weights / gradients, fp32 residual stream: the AMP mode the headline runs in).
 
 Each transformer block is ONE torch.autograd.Function whose backward is written out by hand over the C-ABI ops, so
 that (a) no T x T / intermediate autograd graph exists, (b) parameter gradients of a block are delivered as soon as
@@ -67,18 +68,52 @@ def _zeros(device, *shapes):
     return [buf[a:a + n].view(sh) for a, n, sh in zip(offs, sizes, shapes)]
 
 
-def _wgrad(dy16, x16, out=None):
-    """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K atomics into the zero-filled `out`."""
-    out_f, in_f = dy16.shape[1], x16.shape[1]
-    dw = torch.zeros(out_f, in_f, device=dy16.device, dtype=F32) if out is None else out
-    ops.gemm(dy16, x16, trans_a=True, trans_b=True, out=dw, accumulate=True, splitk=_splitk(out_f, in_f, dy16.shape[0]))
+def _wgrad(dy, x, out=None):
+    """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K atomics into the zero-filled `out`.  bf16 operands go to the
+    transposed-operand MFMA kernel; fp32 operands (exact mode) are transposed first - the fp32 kernel is row.row only."""
+    out_f, in_f = dy.shape[1], x.shape[1]
+    dw = torch.zeros(out_f, in_f, device=dy.device, dtype=F32) if out is None else out
+    sk = _splitk(out_f, in_f, dy.shape[0])
+    if dy.dtype == F32:
+        ops.gemm(ops.transpose_f32(dy), ops.transpose_f32(x), out=dw, accumulate=True, splitk=sk)
+    else:
+        ops.gemm(dy, x, trans_a=True, trans_b=True, out=dw, accumulate=True, splitk=sk)
     return dw
 
 
-def _bgrad(dy16, out=None):
-    db = torch.zeros(dy16.shape[1], device=dy16.device, dtype=F32) if out is None else out
-    ops.colsum_accum(dy16, db)
+def _dgrad(d, w_, **kw):
+    """dx = d . W for a weight stored [out, in] (nn.Linear layout), with the GEMM epilogue options in kw."""
+    if d.dtype == F32:
+        return ops.gemm(d, ops.transpose_f32(w_), **kw)
+    return ops.gemm(d, w_, trans_b=True, **kw)
+
+
+def _bgrad(dy, out=None):
+    db = torch.zeros(dy.shape[1], device=dy.device, dtype=F32) if out is None else out
+    ops.colsum_accum(dy, db)
     return db
+
+
+def _act_grad(t32, adt):
+    """A gradient of the fp32 residual stream as a GEMM operand of the compute dtype."""
+    return t32 if adt == F32 else ops.cast(t32, BF16)
+
+
+def _ln_bwd(adt, x, mean, rstd, w, dg, db, dy, dres=None, dy32=None, dxsum=None, drop=(0.0, 0)):
+    """Backward of a LayerNorm whose input was `x`: dx = LN'(dy [+ dy32]) + dres.  Returns (dx fp32, dx in the compute dtype with the
+    dropout mask `drop` = (p, seed) of the dense layer that produced x re-applied); column sums of the second go to dxsum (that
+    layer's bias gradient).  In bf16 mode all of it is one kernel; in exact mode the pieces are separate launches."""
+    if adt == BF16:
+        return ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dy32=dy32, dres=dres, dxsum=dxsum, drop_seed=drop[1], drop_p=drop[0])
+    if dy32 is not None:
+        raise ValueError("exact mode: fold the second gradient into `dy` with the producing GEMM's residual epilogue")
+    dx32, _ = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy, dres=dres, want_bf16=False)
+    d = dx32
+    if drop[0] > 0:
+        d = ops.dropout_apply_(dx32.clone(), drop[1], drop[0])
+    if dxsum is not None:
+        ops.colsum_accum(d.view(-1, d.shape[-1]), dxsum)
+    return dx32, d
 
 
 # bf16 copy + column sums of a gradient tensor handed from one block's backward to the next (saves a cast pass and a column-sum
@@ -104,12 +139,6 @@ def _take_shadow(t32):
     return sh
 
 
-def _need_bf16(adt, what):
-    if adt != BF16:
-        raise RuntimeError(f"{what}: the backward pass runs in bf16 compute mode only (enable torch.autocast or set "
-                           "SIMSEG_AMD_COMPUTE=bf16); fp32 mode is forward/eval only")
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # generic pieces
 # ------------------------------------------------------------------------------------------------------------------
@@ -129,10 +158,9 @@ class LinearFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        _need_bf16(ctx.adt, "LinearFn")
         xa, wa = ctx.saved_tensors
-        d16 = ops.cast(dy.reshape(-1, dy.shape[-1]).contiguous(), BF16)
-        dx = ops.gemm(d16, wa, trans_b=True, out_dtype=F32).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        d16 = _act_grad(dy.reshape(-1, dy.shape[-1]).contiguous(), ctx.adt)
+        dx = _dgrad(d16, wa, out_dtype=F32).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = _wgrad(d16, xa) if ctx.needs_input_grad[1] else None
         db = _bgrad(d16) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
@@ -179,11 +207,10 @@ class ViTEmbedFn(Function):
 
     @staticmethod
     def backward(ctx, dx):
-        _need_bf16(ctx.adt, "ViTEmbedFn")
         (cols,) = ctx.saved_tensors
         B, N, D = ctx.dims
         dx = dx.contiguous()
-        dp16 = ops.cast(dx[:, 1:].contiguous().view(-1, D), BF16)
+        dp16 = _act_grad(dx[:, 1:].contiguous().view(-1, D), ctx.adt)
         dw = _wgrad(dp16, cols).view(D, 3, 16, 16) if ctx.needs_input_grad[1] else None
         db = _bgrad(dp16) if ctx.needs_input_grad[2] else None
         dcls = dpos = None
@@ -223,36 +250,37 @@ class ViTBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        _need_bf16(ctx.adt, "ViTBlockFn")
         x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_, n1w, n2w = ctx.saved_tensors
         B, T, D = ctx.dims
+        adt = ctx.adt
         need = ctx.needs_input_grad
         dy = dy.contiguous()
-        sh = _take_shadow(dy)
+        sh = _take_shadow(dy) if adt == BF16 else None
         dy = dy.view(-1, D)
         if sh is not None:
             dy16, df2b = sh[0].view(-1, D), sh[1]
         else:
-            dy16 = ops.cast(dy, BF16)
+            dy16 = _act_grad(dy, adt)
             df2b = _bgrad(dy16) if need[14] else None
         (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros(
             dy.device, (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
-        dpre = ops.gemm(dy16, f2w_, trans_b=True, act=4, aux=pre, colsum=df1b)
+        dpre = _dgrad(dy16, f2w_, act=4, aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
-        dln2 = ops.gemm(dpre, f1w_, trans_b=True)
+        dln2 = _dgrad(dpre, f1w_)
         df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
-        dx1_32, dx1_16 = ops.layernorm_bwd(x1, mean2, rstd2, n2w, dn2w, dn2b, dy16=dln2, dres=dy, dxsum=dpb)
+        dx1_32, dx1_16 = _ln_bwd(adt, x1, mean2, rstd2, n2w, dn2w, dn2b, dln2, dres=dy, dxsum=dpb)
         # attention
-        datt = ops.gemm(dx1_16, pw_, trans_b=True)
+        datt = _dgrad(dx1_16, pw_)
         dpw = _wgrad(dx1_16, att.view(-1, D), dpw_z) if need[7] else None
         dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5).view(-1, 3 * D)
-        dln1 = ops.gemm(dqkv, qw_, trans_b=True)
+        dln1 = _dgrad(dqkv, qw_)
         dqw = _wgrad(dqkv, ln1.view(-1, D), dqw_z) if need[5] else None
         dqb = _bgrad(dqkv, dqb_z) if need[6] else None
-        dx, dx16 = ops.layernorm_bwd(x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dy16=dln1, dres=dx1_32, dxsum=dsum)
+        dx, dx16 = _ln_bwd(adt, x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dln1, dres=dx1_32, dxsum=dsum)
         dx = dx.view(B, T, D)
-        _put_shadow(dx, dx16, dsum)
+        if adt == BF16:
+            _put_shadow(dx, dx16, dsum)
         return (dx, None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
 
 
@@ -339,26 +367,30 @@ class BertLayerFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        _need_bf16(ctx.adt, "BertLayerFn")
         (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low) = ctx.saved_tensors
         B, L, D = ctx.dims
+        adt = ctx.adt
         p, seed = ctx.drop
         need = ctx.needs_input_grad
         dy = dy.contiguous().view(-1, D)
         I = pre.shape[1]
         (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros(
             dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
-        ds2_32, d2 = ops.layernorm_bwd(s2, mean_o, rstd_o, low, dlow, dlob, dy32=dy, dxsum=do2b, drop_seed=seed + 2, drop_p=p)
-        dpre = ops.gemm(d2, o2w_, trans_b=True, act=4, aux=pre, colsum=dib)
+        ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt == BF16 else dy, dy32=dy if adt == BF16 else None,
+                             dxsum=do2b, drop=(p, seed + 2))
+        dpre = _dgrad(d2, o2w_, act=4, aux=pre, colsum=dib)
         do2w = _wgrad(d2, act, do2w_z) if need[18] else None
-        da = ops.gemm(dpre, iw_, trans_b=True)
+        # gradient reaching LN_a's output: through the intermediate dense (da) + the residual branch (ds2_32); bf16 mode adds them
+        # inside the LayerNorm kernel, exact mode in the GEMM's residual epilogue
+        da = _dgrad(dpre, iw_) if adt == BF16 else _dgrad(dpre, iw_, residual=ds2_32)
         diw = _wgrad(dpre, aa, diw_z) if need[16] else None
-        ds1_32, d1 = ops.layernorm_bwd(s1, mean_a, rstd_a, law, dlaw, dlab, dy16=da, dy32=ds2_32, dxsum=dob, drop_seed=seed + 1, drop_p=p)
-        datt = ops.gemm(d1, ow_, trans_b=True)
+        ds1_32, d1 = _ln_bwd(adt, s1, mean_a, rstd_a, law, dlaw, dlab, da, dy32=ds2_32 if adt == BF16 else None, dxsum=dob,
+                             drop=(p, seed + 1))
+        datt = _dgrad(d1, ow_)
         dow = _wgrad(d1, att.view(-1, D), dow_z) if need[12] else None
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), att, datt.view(B, L, D), lse, ctx.heads, mask, scale=64 ** -0.5,
                                  drop_seed=seed, drop_p=p).view(-1, 3 * D)
-        dx = ops.gemm(dqkv, wqkv, trans_b=True, residual=ds1_32, out_dtype=F32)
+        dx = _dgrad(dqkv, wqkv, residual=ds1_32, out_dtype=F32)
         dwqkv = _wgrad(dqkv, xa, dwqkv_z) if (need[6] or need[8] or need[10]) else None
         dbqkv = _bgrad(dqkv, dbqkv_z) if (need[7] or need[9] or need[11]) else None
         dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]
@@ -369,8 +401,6 @@ class BertLayerFn(Function):
 
 def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     """m: module tree with HF BertModel parameter names (simseg_amd/nn.py Bert). Returns last_hidden_state [B,L,D] fp32."""
-    if training and (m.hidden_dropout_prob > 0 or m.attention_probs_dropout_prob > 0):
-        _need_bf16(adt, "BERT in train() mode (dropout)")
     p_h = m.hidden_dropout_prob if training else 0.0
     p_a = m.attention_probs_dropout_prob if training else 0.0
     if p_h != p_a:
@@ -410,10 +440,9 @@ class ProjectPoolFn(Function):
 
     @staticmethod
     def backward(ctx, demb):
-        _need_bf16(ctx.adt, "ProjectPoolFn")
         fa, wa, emb, idx, norm = ctx.saved_tensors
         B, N, D = ctx.dims
-        dtok = ops.topk_pool_l2norm_bwd(demb.contiguous(), emb, norm, idx, N, BF16).view(B * N, -1)
-        dfe = ops.gemm(dtok, wa, trans_b=True, out_dtype=F32).view(B, N, D) if ctx.needs_input_grad[0] else None
+        dtok = ops.topk_pool_l2norm_bwd(demb.contiguous(), emb, norm, idx, N, ctx.adt).view(B * N, -1)
+        dfe = _dgrad(dtok, wa, out_dtype=F32).view(B, N, D) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dtok, fa) if ctx.needs_input_grad[1] else None
         return dfe, dw, None, None, None

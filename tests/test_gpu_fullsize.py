@@ -123,7 +123,7 @@ def _cos(a, b):
 
 
 def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
-    """BASELINE config 3's towers at full width and depth (ViT-B/16 @224: T=197, BERT-base L=77, ragged masks), B=6: bf16 forward +
+    """BASELINE config 3's towers at full width and depth (ViT-B/16 @224: T=197, BERT-base L=77, ragged masks), B=6: bf16 (and, last, exact-fp32) forward +
     InfoNCE + backward on the HIP path against the fp32 CPU oracle on the same weights, under both tower schedules (one / two HIP
     streams).  Exercises the GEMM dispatch at D=768, the split-K weight gradients, 3- and 4-wave attention blocks, every fused epilogue.
 
@@ -183,6 +183,29 @@ def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
             print("BAD", b_)
         assert not bad, f"{len(bad)} tensors outside the bar"
         del m
+    # exact mode (a non-AMP run): the same hand-written backward in fp32 arithmetic reproduces the oracle's gradients elementwise -
+    # which pins the backward's ALGEBRA at full size independently of bf16 rounding
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", "1")
+    m = _build_vitb(224)
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m = m.cuda().eval()
+    loss = m({"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})[0]["nce_loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want.item()) < 1e-4 * abs(want.item()), (loss.item(), want.item())
+    worst, bad = 0.0, []
+    for n, p in m.named_parameters():
+        gr = g32[n]
+        if float(gr.norm()) < 1e-6:
+            continue
+        err = float((p.grad.float().cpu() - gr).abs().max() / gr.abs().max())
+        c = _cos(p.grad, gr)
+        worst = max(worst, err)
+        if not (err < 2e-3 and c > 0.99999):
+            bad.append((n, err, c))
+    print(f"fp32 exact mode: worst max-abs gradient error relative to the tensor's max {worst:.2e}")
+    assert not bad, bad
 
 
 def test_vitb_512_window_forward_vs_oracle(monkeypatch):

@@ -384,6 +384,39 @@ def test_attention_bwd(ops, T):
         assert float(g[1, 9:, 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T", [1, 25, 77, 197, 300])
+def test_attention_bwd_fp32_exact(ops, T):
+    """Exact mode (a non-AMP run of the reference trains in fp32): forward and backward in fp32 MFMA against fp64 torch autograd, with
+    the ragged key-padding mask of text batches and with attention dropout (mask regenerated from the hash)."""
+    B, H = 3, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.2)
+    dout = _rand(B, T, H * 64, seed=T + 1)
+    mask = None
+    if T <= 77:
+        mask = torch.zeros(B, T, dtype=torch.long)
+        for b, n in enumerate((T, min(9, T), 1)):
+            mask[b, :n] = 1
+        mask = mask.cuda()
+    for p, seed in ((0.0, 0), (0.1, 1234)):
+        out, lse = ops.attention_fwd(qkv, H, mask, save_lse=True, drop_seed=seed, drop_p=p)
+        dqkv = ops.attention_bwd(qkv, out, dout, lse, H, mask, drop_seed=seed, drop_p=p)
+        keep = torch.ones(B * H * T * T, device="cuda")
+        if p > 0:
+            ops.dropout_apply_(keep, seed, p)
+        keep = keep.view(B, H, T, T).double()
+        x = qkv.double().requires_grad_(True)
+        q, k, v = x.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        sc = (q @ k.transpose(-1, -2)) * 0.125
+        if mask is not None:
+            sc = sc + (1.0 - mask[:, None, None, :].double()) * -10000.0
+        ref = ((sc.softmax(-1) * keep) @ v).transpose(1, 2).reshape(B, T, H * 64)
+        _close(out, ref.detach().float(), 1e-5, f"fp32 attention fwd T={T} p={p}")
+        ref.backward(dout.double())
+        _close(dqkv, x.grad.float(), 2e-5, f"fp32 attention bwd T={T} p={p}")
+        if mask is not None and T > 9:      # padded keys get an exactly-zero K/V gradient
+            assert float(dqkv.view(B, T, 3, H, 64)[1, 9:, 1:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("T", [77, 197, 600])
 def test_attention_deferred_rescale_branch(ops, T):
     """The online softmax raises its running maximum (and rescales O, l) only when a tile's maximum exceeds it by more than a

@@ -154,18 +154,66 @@ def test_train_mode_dropout_runs_and_differs(golden, monkeypatch):
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
-def test_fp32_mode_refuses_backward(golden, monkeypatch):
+def test_train_step_fp32_exact_vs_reference_golden(golden, monkeypatch):
+    """A non-AMP run (cfg.dist.fp16 = False -> plain fp32 loss.backward(), simseg/core/hooks/optimizer.py:76-77): the hand-written
+    backward in exact fp32 arithmetic against the REFERENCE's own fp32 gradients of the same batch - every parameter, elementwise."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
     g = golden("clip_train_ws1")
     m = _build(golden)
+    m.eval()          # the fixture was generated in eval mode (no dropout)
     batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
-    with pytest.raises(RuntimeError, match="bf16 compute mode only"):     # train() mode: refused at the first dropout site
-        m.train()
-        m(batch)
-    m.eval()
+    loss_dict, a1, a2 = m(batch)
+    loss = loss_dict["nce_loss"]
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["r0.loss"]), rtol=2e-5)
+    assert abs(a1.item() - float(g["r0.i2t_acc"])) < 1e-6 and abs(a2.item() - float(g["r0.t2i_acc"])) < 1e-6
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("r0.grad."):
+            continue
+        name = k[len("r0.grad."):]
+        ours, ref = params[name].grad.float().cpu(), tt(g[k])
+        err = float((ours - ref).abs().max() / (ref.abs().max() + 1e-30))
+        worst = max(worst, err)
+        if "key.bias" in name:       # softmax is invariant to a key bias: the true gradient is 0 and both sides hold rounding noise
+            assert float(ours.abs().max()) < 1e-5 * float(params[name.replace("key", "value")].grad.abs().max()) + 1e-9, name
+            continue
+        assert err < 2e-4, (name, err)
+    print("fp32 backward: worst max-abs error relative to the gradient's max", worst)
+
+
+def test_fp32_train_mode_dropout(golden, monkeypatch):
+    """Exact mode with BERT's dropout active: finite, stochastic, and the backward regenerates the forward's masks (a finite
+    difference along the gradient direction, same seed, agrees with the analytic directional derivative)."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    from simseg_amd import nn as snn
+    g = golden("clip_train_ws1")
+    m = _build(golden)
+    m.train()
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    l1 = m(batch)[0]["nce_loss"]
+    l2 = m(batch)[0]["nce_loss"]
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    snn.manual_dropout_seed(1234)
     loss = m(batch)[0]["nce_loss"]
-    with pytest.raises(RuntimeError, match="bf16 compute mode only"):
-        loss.backward()
+    loss.backward()
+    w = [p for n, p in m.named_parameters() if n.endswith("encoder.layer.0.intermediate.dense.weight")][0]
+    gdir = w.grad / w.grad.norm()
+    analytic = float((w.grad * gdir).sum())
+    eps = 2e-2
+    vals = []
+    for sgn in (1.0, -1.0):
+        with torch.no_grad():
+            w.add_(gdir, alpha=sgn * eps)
+        snn.manual_dropout_seed(1234)
+        with torch.no_grad():
+            vals.append(m(batch)[0]["nce_loss"].item())
+        with torch.no_grad():
+            w.add_(gdir, alpha=-sgn * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    print("directional derivative: analytic", analytic, "numeric", numeric)
+    assert abs(numeric - analytic) < 5e-2 * abs(analytic) + 1e-5
 
 
 def test_full_size_vs_oracle(monkeypatch):
