@@ -132,9 +132,29 @@ class _BertEmbeddings(nn.Module):
 
 
 class _BertSelf(nn.Module):
+    """HF BertSelfAttention's parameters: three Linear modules (the names checkpoints and the optimizer's regex rules use).  Their
+    storage is packed back to back - query, key, value - so that the fused [3D, D] projection GEMM and its [3D] bias read the
+    masters in place (towers._as_one) instead of concatenating them every forward.  Re-packed after every device / dtype move."""
+
     def __init__(self, dim):
         super().__init__()
         self.query, self.key, self.value = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
+        self._pack()
+
+    @torch.no_grad()
+    def _pack(self):
+        for attr in ("weight", "bias"):
+            ps = [getattr(m, attr) for m in (self.query, self.key, self.value)]
+            flat = torch.cat([p.data for p in ps])
+            o = 0
+            for p in ps:
+                p.data = flat[o:o + p.shape[0]]
+                o += p.shape[0]
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._pack()
+        return self
 
 
 class _BertDenseLN(nn.Module):

@@ -44,7 +44,14 @@ class AdamW(torch.optim.Optimizer):
             n = p.numel()
             if "m" in st:                     # keep moments across a re-plan / a loaded checkpoint
                 m[o:o + n].copy_(st["m"].reshape(-1)); v[o:o + n].copy_(st["v"].reshape(-1))
-            st["m"], st["v"], st["p16"] = m[o:o + n].view_as(p), v[o:o + n].view_as(p), p16[o:o + n].view_as(p)
+            st["m"], st["v"] = m[o:o + n].view_as(p), v[o:o + n].view_as(p)
+            o += n
+        # bf16 copies: matrices first, in parameter order - the weights of modules that share an input (BERT's query / key / value)
+        # then sit back to back and the towers use them as one [3D, D] operand without a concatenation (towers._wt_stacked)
+        o = 0
+        for p in sorted(params, key=lambda q: q.dim() < 2):
+            n = p.numel()
+            self.state[p]["p16"] = p16[o:o + n].view_as(p)
             o += n
         tid, coff = [], []
         for t, p in enumerate(params):

@@ -30,6 +30,7 @@ def invalidate_weight_cache():
     """Drop every cached bf16 weight copy.  Needed only after writes torch cannot see (in-place ops on `param.data`, which
     carry their own version counter); load_state_dict / copy_ / optimizers / .to() are detected without it."""
     _W16.clear()
+    _CAT.clear()
 
 
 def _wt(w, adt):
@@ -48,6 +49,42 @@ def _wt(w, adt):
                 del _W16[k]
         _W16[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), w16)
     return w16
+
+
+def _as_one(*ts):
+    """The tensors as ONE tensor (rows stacked) when they already lie back to back in the same storage, else None."""
+    a = ts[0]
+    base, off = a.untyped_storage().data_ptr(), a.storage_offset()
+    for t in ts:
+        if (t.dtype != a.dtype or t.shape[1:] != a.shape[1:] or not t.is_contiguous() or t.untyped_storage().data_ptr() != base
+                or t.storage_offset() != off):
+            return None
+        off += t.numel()
+    return torch.as_strided(a, (sum(t.shape[0] for t in ts),) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+
+_CAT = {}      # id(first parameter) -> (the _W16 entries the concatenation was made from, concatenated bf16 weight)
+
+
+def _wt_stacked(ws, adt):
+    """[sum out, in] weight of several nn.Linear modules that share their input (HF keeps BERT's query / key / value as three
+    modules; one GEMM computes all three).  No copy when the operands are adjacent in memory: the fp32 masters are packed by the module
+    (nn._BertSelf), the bf16 copies by the optimizer (optim.AdamW lays matrices out in parameter order).  Otherwise (bf16 without our
+    optimizer: evaluation) the concatenation is made once and reused until one of the bf16 copies is refreshed."""
+    parts = [_wt(w, adt) for w in ws]
+    one = _as_one(*parts)
+    if one is not None:
+        return one
+    if adt == BF16:
+        ents = [_W16.get(id(w)) for w in ws]
+        hit = _CAT.get(id(ws[0]))
+        if hit is not None and all(e is not None and e is h for e, h in zip(ents, hit[0])):
+            return hit[1]
+        cat = torch.cat(parts)
+        if all(e is not None for e in ents):
+            _CAT[id(ws[0])] = (ents, cat)
+        return cat
+    return torch.cat(parts)
 
 
 def _splitk(m, n, k_rows):
@@ -347,8 +384,10 @@ class BertLayerFn(Function):
         x = x.contiguous()
         save = any(ctx.needs_input_grad)
         xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
-        wqkv = torch.cat([_wt(qw, adt), _wt(kw, adt), _wt(vw, adt)])       # HF keeps three matrices; one fused [3D, D] GEMM here
-        bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
+        wqkv = _wt_stacked((qw, kw, vw), adt)                              # HF keeps three matrices; one fused [3D, D] GEMM here
+        bqkv = _as_one(qb.detach(), kb.detach(), vb.detach())
+        if bqkv is None:
+            bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
         ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
         qkv = ops.gemm(xa, wqkv, bias=bqkv)
         att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p)

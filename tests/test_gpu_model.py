@@ -216,6 +216,45 @@ def test_fp32_train_mode_dropout(golden, monkeypatch):
     assert abs(numeric - analytic) < 5e-2 * abs(analytic) + 1e-5
 
 
+def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monkeypatch):
+    """(a) After the fused AdamW has written its bf16 copies, BERT's [3D, D] query/key/value operand is a view of the optimizer's buffer
+    (no per-forward concatenation); before that - and in evaluation - the concatenation is made once and reused.
+    (b) The reference's AMP step `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`
+    (simseg/core/hooks/optimizer.py:73-82) runs unmodified over this model + optimizer: with bf16 compute the scale is a power of
+    two and cancels, so the parameters after the step equal those of the unscaled step."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    from simseg_amd import towers
+    from simseg_amd.optim import AdamW
+    g = golden("clip_train_ws1")
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    results = []
+    for use_scaler in (False, True):
+        m = _build(golden)
+        m.eval()
+        opt = AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0, enabled=use_scaler)
+        sa = [mod for n, mod in m.named_modules() if n.endswith("encoder.layer.0.attention.self")][0]
+        ws = (sa.query.weight, sa.key.weight, sa.value.weight)
+        with torch.no_grad():
+            m(batch)
+        first = towers._wt_stacked(ws, torch.bfloat16)
+        assert towers._wt_stacked(ws, torch.bfloat16) is first                      # evaluation: one concatenation, reused
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = m(batch)[0]["nce_loss"]
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        w3 = towers._wt_stacked(ws, torch.bfloat16)
+        assert w3.data_ptr() == opt.state[sa.query.weight]["p16"].data_ptr() and w3.shape == (3 * ws[0].shape[0], ws[0].shape[1])
+        assert torch.equal(w3[ws[0].shape[0]:2 * ws[0].shape[0]], sa.key.weight.detach().bfloat16())      # current values, in place
+        torch.cuda.synchronize()
+        results.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    worst = max(float((results[0][n] - results[1][n]).abs().max()) for n in results[0])
+    print("max parameter difference, GradScaler step vs plain step:", worst)
+    assert worst < 1e-6
+
+
 def test_full_size_vs_oracle(monkeypatch):
     """ViT-S @224 + BERT-base on config-1-shaped input (4 images, 20 prompts): kernels vs the CPU oracle."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")

@@ -188,3 +188,34 @@ def test_pretrained_tower_weights_resample_pos_embed_or_fail_loudly(tmp_path, mo
     ref = golden("interp_pe")                                     # the resampling itself is pinned against the reference's function
     fake = SimpleNamespace(patch_embed=SimpleNamespace(num_patches=18 * 18), pos_embed=torch.zeros(1, 1 + 18 * 18, 96))
     assert np.allclose(interpolate_pos_embed(torch.from_numpy(ref["pe"]), fake).numpy(), ref["pe_18"], atol=1e-6)
+
+
+def test_bert_qkv_parameters_are_packed_back_to_back():
+    """HF names are kept (three Linear modules) but query / key / value live adjacent in one buffer, so the fused projection reads them
+    in place; the packing survives dtype / device moves and in-place state-dict loads, and a broken packing is detected (-> concatenation)."""
+    from simseg_amd.nn import Bert
+    from simseg_amd.towers import _as_one
+    m = Bert("bert-test")
+    s = m.encoder.layer[1].attention.self
+    D = s.query.weight.shape[0]
+
+    def stacked():
+        w = _as_one(s.query.weight.detach(), s.key.weight.detach(), s.value.weight.detach())
+        b = _as_one(s.query.bias.detach(), s.key.bias.detach(), s.value.bias.detach())
+        return w, b
+
+    w, b = stacked()
+    assert w is not None and b is not None and w.shape == (3 * D, D) and b.shape == (3 * D,)
+    assert torch.equal(w[D:2 * D], s.key.weight) and torch.equal(b[2 * D:], s.value.bias)
+    names = [n for n, _ in m.named_parameters()]
+    assert "encoder.layer.1.attention.self.key.weight" in names               # HF naming unchanged
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items() if v.is_floating_point()}
+    m.load_state_dict(sd, strict=False)
+    w, b = stacked()
+    assert w is not None and torch.equal(w[:D], sd["encoder.layer.1.attention.self.query.weight"])
+    m = m.double()
+    s = m.encoder.layer[1].attention.self
+    w, b = stacked()
+    assert w is not None and w.dtype == torch.float64 and torch.equal(w[2 * D:].float(), sd["encoder.layer.1.attention.self.value.weight"])
+    s.key.weight.data = s.key.weight.data.clone()                             # someone re-homes a tensor: no longer one block
+    assert stacked()[0] is None
