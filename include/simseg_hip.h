@@ -49,10 +49,10 @@ int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M
                           int normalize, void* stream);
 
 /* Kernel selection for benchmarking / tests (thread-local; production callers never call it): 0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring kernel,
- * 3 = 256x256 ping-pong kernel (+100: debug, epilogue skipped and a cycle-counter timeline written to C by
+ * 3 = 256x256 ping-pong kernel, 4 = small-problem kernel (32x64 / 64x64 tiles, intra-block split-K) wherever it applies (+100: debug, epilogue skipped and a cycle-counter timeline written to C by
  * tools/dbg_gemm_timeline.py). */
 int simseg_set_gemm_variant(int v);
-/* Which of those kernels (1 / 2 / 3) the calling thread's last simseg_gemm launched. */
+/* Which of those kernels (1 / 2 / 3 / 4) the calling thread's last simseg_gemm launched. */
 int simseg_gemm_last_variant(void);
 
 /* LayerNorm over the last dim of x[rows,D] (fp32 residual stream) -> y (out_dtype) and optionally a bf16 copy.

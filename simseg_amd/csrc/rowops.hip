@@ -386,15 +386,27 @@ __global__ void topk_pool_slice_kernel(const TI* __restrict__ tok, const long* _
 #pragma unroll
     for (int j = 0; j < POOL_MAXK; ++j) { tv[j] = -INFINITY; ti[j] = 0; }
     const TI* base = tok + (long)b * N * P + c;
-    for (int n = n0; n < n1; ++n) {
-        float v = (float)base[(long)n * P];
-        if (mask && mask[(long)b * N + n] == 0) v = -10000.f;
-        if (v > tv[k - 1]) {
-            float x = v; int xi = n;
-            bool ins = false;
+    for (int nb = n0; nb < n1; nb += 8) {             // eight independent loads in flight, then the (serial) insertions
+        float vs[8];
 #pragma unroll
-            for (int j = 0; j < POOL_MAXK; ++j)
-                if (j < k && (ins || x > tv[j])) { const float t = tv[j]; const int u = ti[j]; tv[j] = x; ti[j] = xi; x = t; xi = u; ins = true; }
+        for (int u = 0; u < 8; ++u) {
+            const int n = nb + u;
+            float v = -INFINITY;
+            if (n < n1) {
+                v = (float)base[(long)n * P];
+                if (mask && mask[(long)b * N + n] == 0) v = -10000.f;
+            }
+            vs[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (vs[u] > tv[k - 1]) {
+                float x = vs[u]; int xi = nb + u;
+                bool ins = false;
+#pragma unroll
+                for (int j = 0; j < POOL_MAXK; ++j)
+                    if (j < k && (ins || x > tv[j])) { const float t = tv[j]; const int w = ti[j]; tv[j] = x; ti[j] = xi; x = t; xi = w; ins = true; }
+            }
         }
     }
 #pragma unroll
@@ -405,23 +417,52 @@ __global__ void topk_pool_slice_kernel(const TI* __restrict__ tok, const long* _
         }
 }
 
-__global__ void topk_pool_merge_kernel(const float* __restrict__ cv, const int* __restrict__ ci, float* __restrict__ emb, int* __restrict__ idx,
-                                       float* __restrict__ norm_out, int P, int k, float eps, int normalize) {
+// Merge of sorted candidate lists, in (value desc, index asc) order.  cv / ci: [B, L, k, P].  Block (b, g) merges lists
+// g*LPG .. g*LPG + LPG - 1.  Two launches: POOL_SLICES lists -> POOL_GROUPS lists (FINAL = false: the merged list is written back
+// out as [B, POOL_GROUPS, k, P]), then those -> the pooled, normalised embedding (FINAL = true).  One pass over all POOL_SLICES * k
+// candidates in a single block per image was 133 us of a 1.5 ms batch-1 forward.
+constexpr int POOL_GROUPS = 4;
+template <bool FINAL>
+__global__ void topk_pool_merge_kernel(const float* __restrict__ cv, const int* __restrict__ ci, float* __restrict__ ov, int* __restrict__ oi,
+                                       float* __restrict__ emb, int* __restrict__ idx, float* __restrict__ norm_out, int L, int LPG,
+                                       int P, int k, float eps, int normalize) {
     __shared__ float sh[16];
-    const int b = blockIdx.x, c = threadIdx.x;
+    const int b = blockIdx.x, g = blockIdx.y, c = threadIdx.x;
     float tv[POOL_MAXK];
     int ti[POOL_MAXK];
 #pragma unroll
     for (int j = 0; j < POOL_MAXK; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-    for (int m = 0; m < POOL_SLICES * k; ++m) {
-        const long o = ((long)b * POOL_SLICES * k + m) * P + c;
-        float x = cv[o];
-        int xi = ci[o];
-        if (x == -INFINITY) continue;                 // empty slot of a short slice
-        bool ins = false;
+    const int M = LPG * k;
+    const long base = ((long)b * L + (long)g * LPG) * k;
+    constexpr int MB = 8;                             // candidate loads in flight per round trip
+    for (int mb = 0; mb < M; mb += MB) {
+        float xs[MB];
+        int is[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            const long o = (base + min(mb + u, M - 1)) * P + c;
+            xs[u] = mb + u < M ? cv[o] : -INFINITY;
+            is[u] = ci[o];
+        }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            float x = xs[u];
+            int xi = is[u];
+            if (x == -INFINITY) continue;             // empty slot of a short slice
+            bool ins = false;
+#pragma unroll
+            for (int j = 0; j < POOL_MAXK; ++j)
+                if (j < k && (ins || x > tv[j] || (x == tv[j] && xi < ti[j]))) { const float t = tv[j]; const int w = ti[j]; tv[j] = x; ti[j] = xi; x = t; xi = w; ins = true; }
+        }
+    }
+    if (!FINAL) {
 #pragma unroll
         for (int j = 0; j < POOL_MAXK; ++j)
-            if (j < k && (ins || x > tv[j] || (x == tv[j] && xi < ti[j]))) { const float t = tv[j]; const int u = ti[j]; tv[j] = x; ti[j] = xi; x = t; xi = u; ins = true; }
+            if (j < k) {
+                const long o = (((long)b * gridDim.y + g) * k + j) * P + c;
+                ov[o] = tv[j]; oi[o] = ti[j];
+            }
+        return;
     }
     float s = 0.f;
 #pragma unroll
@@ -644,7 +685,7 @@ extern "C" int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, co
     return 0;
 }
 
-extern "C" int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k) { return B * POOL_SLICES * k * P * 2; }
+extern "C" int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k) { return B * (POOL_SLICES + POOL_GROUPS) * k * P * 2; }
 
 extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
                                            float* scratch, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize,
@@ -656,12 +697,17 @@ extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int
     if (scratch) {       // small batches: token slices in parallel, then a merge
         float* cv = scratch;
         int* ci = reinterpret_cast<int*>(scratch + B * POOL_SLICES * k * P);
+        float* gv = scratch + 2 * B * POOL_SLICES * k * P;
+        int* gi = reinterpret_cast<int*>(gv + B * POOL_GROUPS * k * P);
         dim3 g((unsigned)B, POOL_SLICES);
         if (dtype == 0)
             hipLaunchKernelGGL(topk_pool_slice_kernel<float>, g, dim3((unsigned)P), 0, STREAM, (const float*)tok, (const long*)mask, cv, ci, (int)N, (int)P, k);
         else
             hipLaunchKernelGGL(topk_pool_slice_kernel<bf16_t>, g, dim3((unsigned)P), 0, STREAM, (const bf16_t*)tok, (const long*)mask, cv, ci, (int)N, (int)P, k);
-        hipLaunchKernelGGL(topk_pool_merge_kernel, dim3((unsigned)B), dim3((unsigned)P), 0, STREAM, cv, ci, emb, idx, norm, (int)P, k, eps, normalize);
+        hipLaunchKernelGGL(topk_pool_merge_kernel<false>, dim3((unsigned)B, POOL_GROUPS), dim3((unsigned)P), 0, STREAM, cv, ci, gv, gi, emb, idx, norm,
+                           POOL_SLICES, POOL_SLICES / POOL_GROUPS, (int)P, k, eps, normalize);
+        hipLaunchKernelGGL(topk_pool_merge_kernel<true>, dim3((unsigned)B, 1), dim3((unsigned)P), 0, STREAM, gv, gi, gv, gi, emb, idx, norm,
+                           POOL_GROUPS, POOL_GROUPS, (int)P, k, eps, normalize);
         SS_LAUNCH_CHECK("topk_pool_fwd(sliced)");
         return 0;
     }

@@ -37,7 +37,7 @@ def _push_variant(kind):
 
 
 def set_gemm_variant(v):
-    """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring, 3 = 256x256 ping-pong (tests / benchmarks only)."""
+    """0 auto, 1 = 128x128 register-staged kernel, 2 = 256x256 direct-to-LDS ring, 3 = 256x256 ping-pong, 4 = small-problem kernel wherever it applies (tests / benchmarks only)."""
     _VARIANT["gemm"] = int(v)
     _push_variant("gemm")
 
@@ -79,7 +79,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         e1.record()
         kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
         kind += "_o32" if out.dtype == torch.float32 else "_o16"
-        kind += {1: "", 2: "_L", 3: "_P"}[raw("simseg_gemm_last_variant")]      # the kernel the library actually launched
+        kind += {1: "", 2: "_L", 3: "_P", 4: "_S", 5: "_R"}[raw("simseg_gemm_last_variant")]      # the kernel the library actually launched
         PROFILE.append((kind, 2.0 * M * N * K, e0, e1))
     return out
 

@@ -84,6 +84,52 @@ def test_gemm_f32_epilogues(ops):
     _close(cs, (a.bfloat16().float() @ b.bfloat16().float().T + bias).sum(0), 1e-4, "epilogue column sums (bf16, pre-rounding values)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(325, 384, 384), (325, 1152, 384), (1025, 768, 768), (1025, 768, 3072), (1025, 3072, 768), (325, 21, 512),
+                                   (1, 512, 768), (7, 70, 64), (64, 64, 128), (33, 65, 1024)])
+def test_gemm_small_problem_kernel(ops, dtype, M, N, K):
+    """The batch-1 shapes of the reference's segmentation tool (one 288^2 / 512^2 image: 325 / 1025 token rows): 32x64 / 64x64 tiles with the
+    K slab split between wave groups.  Auto-dispatch takes it for these shapes; results and every fused epilogue against fp64 torch,
+    and the dropout mask is the 128x128 kernel's (same element hash)."""
+    from simseg_amd.lib import raw
+    a, b = _rand(M, K, seed=1, dtype=dtype), _rand(N, K, seed=2, scale=K ** -0.5, dtype=dtype)      # products of O(1)
+    ref = (a.double() @ b.double().T).float()
+    tol = 1e-5
+    ops.gemm(a, b, out_dtype=torch.float32)
+    auto = raw("simseg_gemm_last_variant")
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    assert auto == (4 if t128 < (200 if dtype == torch.float32 else 160) else (5 if (dtype == torch.bfloat16 and t128 <= 256) else 1))
+    ops.set_gemm_variant(4)
+    try:
+        out = ops.gemm(a, b, out_dtype=torch.float32)
+        assert raw("simseg_gemm_last_variant") == 4
+        _close(out, ref, tol, f"small {M}x{N}x{K}")
+        bias, res, rs = _rand(N, seed=3), _rand(M, N, seed=4), _rand(M, seed=5).abs() + 0.5
+        dact = torch.empty(M, N, device="cuda", dtype=dtype)
+        got = ops.gemm(a, b, bias=bias, act=3, aux_out=dact)
+        x = (ref + bias).requires_grad_(True)
+        F.gelu(x).backward(torch.ones_like(x))
+        _close(got, F.gelu(ref + bias), tol if dtype == torch.float32 else 1e-2, "gelu")
+        _close(dact, x.grad, tol if dtype == torch.float32 else 1e-2, "saved GELU'")
+        cs = torch.zeros(N, device="cuda")
+        y = ops.gemm(a, b, alpha=0.5, rowscale=rs, bias=bias, residual=res, out_dtype=torch.float32, colsum=cs)
+        _close(y, ref * 0.5 * rs[:, None] + bias + res, tol, "alpha/rowscale/bias/residual")
+        _close(cs, y.sum(0), 1e-4, "column sums")
+        acc = _rand(M, N, seed=7)
+        want = acc + ref
+        _close(ops.gemm(a, b, out=acc, accumulate=True), want, tol, "accumulate")
+        d4 = ops.gemm(a, b, bias=bias, out_dtype=torch.float32, drop_seed=99, drop_p=0.25)
+        ops.set_gemm_variant(1)
+        d1 = ops.gemm(a, b, bias=bias, out_dtype=torch.float32, drop_seed=99, drop_p=0.25)
+        assert raw("simseg_gemm_last_variant") == 1
+        o1 = ops.gemm(a, b, out_dtype=torch.float32)
+    finally:
+        ops.set_gemm_variant(0)
+    assert float(((d4 == 0) != (d1 == 0)).float().mean()) < 1e-4      # the same mask (an exactly-zero sum aside)
+    _close(d4, d1, tol, "dropout epilogue, both kernels")
+    _close(out, o1, tol, "both kernels")
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 256, 200), (768, 776, 1000), (72, 40, 24)])
 def test_gemm_bf16_layouts(ops, ta, tb, M, N, K):

@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(path, top=40):
+def main(path, top=40, skip=0.0):
     c = sqlite3.connect(path)
     tables = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     disp = next(t for t in tables if t.startswith("rocpd_kernel_dispatch"))
@@ -15,7 +15,9 @@ def main(path, top=40):
     name_col = "kernel_name" if "kernel_name" in scols else "display_name"
     q = f"select s.{name_col}, d.start, d.end from {disp} d join {sym} s on d.kernel_id = s.id"
     agg = {}
-    for name, s, e in c.execute(q):
+    rows = sorted(c.execute(q), key=lambda r: r[1])
+    rows = rows[int(len(rows) * skip):]          # skip > 0: only the tail of the timeline (e.g. the graph-replay phase of a run)
+    for name, s, e in rows:
         name = re.sub(r"\(.*", "", name)
         name = re.sub(r"^void ", "", name)
         a = agg.setdefault(name, [0, 0])
@@ -29,4 +31,4 @@ def main(path, top=40):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40, float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
