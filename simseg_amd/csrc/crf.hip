@@ -7,10 +7,11 @@
 // permutohedral lattice (Adams, Baek & Davis 2010) with symmetric normalisation - restated for the CPU in oracle/crf_ref.py
 // (pydensecrf itself is not available in this image; the restatement is pinned against an exact O(N^2) mean-field).
 //
-// HBM-bound byte / index work (no MFMA): per image the two lattices are built once and shared by all candidate maps (channels):
+// HBM-bound byte / index work (no MFMA): per image the bilateral lattice is built once and shared by all candidate maps (channels); the
+// spatial lattice depends on the image size only and is built once per call for the whole batch:
 //   simplex   : one thread per pixel - elevate the feature vector, round to the remainder-0 point, rank, barycentric weights; the
 //               d+1 simplex vertices are packed into one 64-bit key each and inserted into an open-addressing hash table (CAS)
-//   assign    : every occupied slot draws a dense lattice-point id; neighbours: 2 (d+1) hash look-ups per lattice point
+//   assign    : every lattice point draws a dense id in the raster order of the pixels that created it; neighbours: 2 (d+1) hash look-ups per point
 //   lists     : per lattice point the (pixel, vertex) entries that touch it (count, wave-scan segment allocation, fill), once
 //   filter    : splat as a GATHER over those lists (plain loads, no float atomics), d+1 blur passes over the lattice points
 //               (new = old + (n1 + n2) / 2, ping-pong buffers, row 0 = the zero "missing neighbour"), slice
@@ -47,11 +48,13 @@ __device__ __forceinline__ unsigned crf_hash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return (unsigned)x;
 }
+// returns the slot of `key`, with bit 31 set when THIS call created the entry (exactly one caller per lattice point does)
 __device__ __forceinline__ int crf_insert(unsigned long long* hkeys, unsigned mask, unsigned long long key) {
     unsigned slot = crf_hash(key) & mask;
     for (;;) {
         const unsigned long long prev = atomicCAS(hkeys + slot, CRF_EMPTY, key);
-        if (prev == CRF_EMPTY || prev == key) return (int)slot;
+        if (prev == CRF_EMPTY) return (int)(slot | 0x80000000u);
+        if (prev == key) return (int)slot;
         slot = (slot + 1) & mask;
     }
 }
@@ -140,23 +143,26 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
             key[k] = (int)rintf(rem0[k]) + (rank[k] <= D - r ? r : r - (D + 1));        // canonical simplex, remainder r
             bad = bad || key[k] < -(1 << (KeyBits<D>::B - 1)) || key[k] >= (1 << (KeyBits<D>::B - 1));
         }
-        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key, img));  // hash slot for now; dense id after crf_assign
+        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key, img));  // hash slot (+ creator bit) for now; dense id after crf_assign
         bary[(long)i * (D + 1) + r] = bc[r];
     }
     if (bad) atomicExch(overflow, 1);
 }
 
-// every occupied hash slot draws a dense lattice-point id.  A thread looks at 16 slots, a wave draws ONE range from the counter
-// (prefix sums inside the wave): a per-slot - and even a per-wave-of-64-slots - atomicAdd on the single counter word serialised
-// ~1 M same-address atomics (5 ms per lattice of a 16-image batch).
-__global__ __launch_bounds__(256) void crf_assign_kernel(const unsigned long long* __restrict__ hkeys, long cap, int* __restrict__ hid,
-                                                         unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
-    const long s0 = (long)blockIdx.x * 4096 + threadIdx.x;       // slots s0 + 256 j, j < 16
+// Every lattice point draws a dense id, in the order of the (pixel, vertex) entries that CREATED the points (bit 31 of off[]): points
+// are then numbered along the image raster, so the value rows a pixel's slice reads, the pixels a point's gather reads and most blur
+// neighbours lie close together in memory (numbering in hash-slot order scattered all three over the whole array).  A thread looks at
+// 16 consecutive entries, a wave draws ONE range from the counter (prefix sums inside the wave; a per-entry atomicAdd on the single
+// counter word serialises millions of same-address atomics).
+__global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__ off, long nv, const unsigned long long* __restrict__ hkeys,
+                                                         int* __restrict__ hid, unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
+    const long e0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+    int slots[16];
     int n = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const long s = s0 + 256 * j;
-        n += (s < cap && hkeys[s] != CRF_EMPTY) ? 1 : 0;
+        slots[j] = e0 + j < nv ? off[e0 + j] : 0;
+        n += slots[j] < 0 ? 1 : 0;
     }
     int incl = n;
 #pragma unroll
@@ -168,21 +174,19 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const unsigned long lon
     if ((threadIdx.x & 63) == 63 && incl) base = atomicAdd(M, incl);
     int id = __shfl(base, 63, 64) + incl - n;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const long s = s0 + 256 * j;
-        if (s < cap) {
-            const unsigned long long k = hkeys[s];
-            if (k != CRF_EMPTY) { hid[s] = id; pkeys[id] = k; ++id; }
+    for (int j = 0; j < 16; ++j)
+        if (slots[j] < 0) {
+            const int slot = slots[j] & 0x7fffffff;
+            hid[slot] = id; pkeys[id] = hkeys[slot]; ++id;
         }
-    }
 }
 
 // ---- the splat as a gather: per lattice point the list of (pixel, vertex) entries that touch it, built once per lattice
 // (count -> segment allocation -> fill), so that each of the ~10 filter applications of a CRF sums its values with plain loads
 // instead of 6 (d = 5) float atomics per pixel and channel (the atomic splat was 1.8 ms per filter of a 16-image batch)
-__global__ __launch_bounds__(256) void crf_count_kernel(const int* __restrict__ off, int* __restrict__ cnt, long nv) {
+__global__ __launch_bounds__(256) void crf_count_kernel(const int* __restrict__ off, int* __restrict__ cnt, int* __restrict__ rank, long nv) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < nv) atomicAdd(cnt + off[e], 1);
+    if (e < nv) rank[e] = atomicAdd(cnt + off[e], 1);             // the entry's position in its point's list: the fill needs no second atomic
 }
 __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ cnt, int* __restrict__ start, const int* __restrict__ M,
                                                         int* __restrict__ cursor) {
@@ -200,35 +204,56 @@ __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ 
     if (m < *M) start[m] = base + incl - n;
 }
 __global__ __launch_bounds__(256) void crf_fill_kernel(const int* __restrict__ off, const float* __restrict__ bary, const int* __restrict__ start,
-                                                       int* __restrict__ fill, int* __restrict__ ent, float* __restrict__ entw, long nv, int d1) {
+                                                       const int* __restrict__ rank, int* __restrict__ ent, float* __restrict__ entw, long nv, int d1) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= nv) return;
     const int m = off[e];
-    const int slot = start[m] + atomicAdd(fill + m, 1);
+    const int slot = start[m] + rank[e];
     ent[slot] = (int)(e / d1);                                    // the pixel; its barycentric weight rides along (sequential reads later)
     entw[slot] = bary[e];
 }
 // val[(m + 1) * C + c] = sum over the entries e of point m of bary[e] * scale[pixel] * in[pixel * C + c]   (pixel = e / (D + 1))
+// G lanes per lattice point walk its list together (a point of the bilateral lattice has ~10-25 entries, of the spatial one more): the
+// list reads are contiguous per group instead of one cache line per lane, and the partial sums meet in a shuffle tree.
 template <int D>
 __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict__ in, const float* __restrict__ scale, const int* __restrict__ start,
                                                          const int* __restrict__ cnt, const int* __restrict__ ent, const float* __restrict__ entw,
-                                                         float* __restrict__ val, const int* __restrict__ M, int C) {
-    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < *M; m += (long)gridDim.x * 256) {
+                                                         float* __restrict__ val, const int* __restrict__ M, int C, long in_stride, long val_stride) {
+    constexpr int G = D == 2 ? 16 : 8;
+    const int sub = threadIdx.x & (G - 1);
+    if (in) in += (long)blockIdx.y * in_stride;                   // blockIdx.y: images that SHARE this lattice (the spatial one), see crf_filter
+    val += (long)blockIdx.y * val_stride;
+    const long Mr = ((long)*M + 256 / G - 1) / (256 / G) * (256 / G);            // whole groups stay together through the shuffles
+    for (long m = ((long)blockIdx.x * 256 + threadIdx.x) / G; m < Mr; m += (long)gridDim.x * (256 / G)) {
         float acc[CRF_MAXC];
-        for (int c = 0; c < C; ++c) acc[c] = 0.f;
-        const int s0 = start[m], n = cnt[m];
-        for (int j = 0; j < n; ++j) {
+#pragma unroll
+        for (int c = 0; c < CRF_MAXC; ++c) acc[c] = 0.f;
+        const bool live = m < *M;
+        const int s0 = live ? start[m] : 0, n = live ? cnt[m] : 0;
+        for (int j = sub; j < n; j += G) {
             const long px = ent[s0 + j];
             const float w = entw[s0 + j] * (scale ? scale[px] : 1.0f);
-            for (int c = 0; c < C; ++c) acc[c] += w * (in ? in[px * C + c] : 1.0f);
+#pragma unroll
+            for (int c = 0; c < CRF_MAXC; ++c)
+                if (c < C) acc[c] += w * (in ? in[px * C + c] : 1.0f);
         }
-        for (int c = 0; c < C; ++c) val[(m + 1) * C + c] = acc[c];
+#pragma unroll
+        for (int c = 0; c < CRF_MAXC; ++c)
+            if (c < C) {
+#pragma unroll
+                for (int o = G / 2; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+            }
+        if (live && sub == 0) {
+#pragma unroll
+            for (int c = 0; c < CRF_MAXC; ++c)
+                if (c < C) val[(m + 1) * C + c] = acc[c];
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off, const int* __restrict__ hid, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) off[i] = hid[off[i]];
+    if (i < n) off[i] = hid[off[i] & 0x7fffffff];
 }
 
 template <int D>
@@ -251,7 +276,9 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long 
 }
 
 __global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ nbj,
-                                                       const int* __restrict__ M, int C) {
+                                                       const int* __restrict__ M, int C, long val_stride) {
+    src += (long)blockIdx.y * val_stride;
+    dst += (long)blockIdx.y * val_stride;
     const long total = (long)*M * C;                              // (the launch is sized for a typical lattice, not the worst case)
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
         const long i = t / C;
@@ -264,9 +291,12 @@ __global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__
 // slice: out[i * C + c] = scale_i * alpha * sum_r bary * val[(off + 1) * C + c]
 template <int D>
 __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ val, const float* __restrict__ scale, const int* __restrict__ off,
-                                                        const float* __restrict__ bary, float* __restrict__ out, long N, int C, int sqrt_norm) {
+                                                        const float* __restrict__ bary, float* __restrict__ out, long N, int C, int sqrt_norm,
+                                                        long val_stride, long out_stride) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    val += (long)blockIdx.y * val_stride;
+    out += (long)blockIdx.y * out_stride;
     const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
     float acc[CRF_MAXC];
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict
     const long i = t / C;
     const int c = (int)(t % C);
     const float g1 = fg[t], b1 = fb[t];
-    const float t0 = -u[t * 2] + wg * (kng[i] - g1) + wb * (knb[i] - b1);
+    const float t0 = -u[t * 2] + wg * (kng[i % N] - g1) + wb * (knb[i] - b1);     // (the spatial lattice is one image's, shared)
     const float t1 = -u[t * 2 + 1] + wg * g1 + wb * b1;
     const float mx = fmaxf(t0, t1);
     const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
@@ -343,11 +373,12 @@ long crf_cap(long n) {
 }
 
 // the same carving serves the size query (base == nullptr) and the launch
-void crf_carve(CrfLayout& L, char* base, long N, int C, CrfLattice (&lat)[2], float*& val0, float*& val1, float*& q1, float*& u, float*& fg,
+void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&lat)[2], float*& val0, float*& val1, float*& q1, float*& u, float*& fg,
                float*& fb, int*& flags) {
     const int dims[2] = {2, 5};
+    const long npx[2] = {N1, N};              // the spatial lattice is one image's (N1 pixels), the bilateral one spans the batch (N)
     for (int k = 0; k < 2; ++k) {
-        const long nv = N * (dims[k] + 1);
+        const long nv = npx[k] * (dims[k] + 1);
         lat[k].cap = crf_cap(nv);
         lat[k].mmax = nv;
         lat[k].off = L.carve<int>(base, nv);
@@ -356,9 +387,9 @@ void crf_carve(CrfLayout& L, char* base, long N, int C, CrfLattice (&lat)[2], fl
         lat[k].hid = L.carve<int>(base, lat[k].cap);
         lat[k].pkeys = L.carve<unsigned long long>(base, nv);
         lat[k].nb = L.carve<int>(base, nv * (dims[k] + 1) * 2);
-        lat[k].norm = L.carve<float>(base, N);
-        lat[k].kn = L.carve<float>(base, N);
-        lat[k].cnt = L.carve<int>(base, 2 * nv);              // counts, then the fill cursors
+        lat[k].norm = L.carve<float>(base, npx[k]);
+        lat[k].kn = L.carve<float>(base, npx[k]);
+        lat[k].cnt = L.carve<int>(base, 2 * nv);              // counts per point, then the rank of every entry in its point's list
         lat[k].start = L.carve<int>(base, nv);
         lat[k].ent = L.carve<int>(base, nv);
         lat[k].entw = L.carve<float>(base, nv);
@@ -380,20 +411,26 @@ unsigned crf_blocks(long work) {
     return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
+// One filter application K(scale_in * in) * scale_out over `nimg` images that share the lattice `lt` (N pixels each; in / out are
+// [image][pixel][C], scale arrays [pixel]): the bilateral lattice covers the whole batch (nimg = 1, N = all pixels), the spatial one is
+// one image's and serves every image of the batch through blockIdx.y.
 template <int D>
 void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, long N,
-                int C, int sqrt_norm, hipStream_t s) {
-    (void)hipMemsetAsync(val0, 0, (size_t)C * sizeof(float), s);                // row 0 = the zero "missing neighbour", both buffers
-    (void)hipMemsetAsync(val1, 0, (size_t)C * sizeof(float), s);
-    hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent, lt.entw, val0, lt.M, C);
+                int C, int sqrt_norm, int nimg, hipStream_t s) {
+    const long vstride = (N * (D + 1) + 1) * (long)C;
+    (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
+    (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);
+    hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent, lt.entw, val0, lt.M,
+                       C, N * C, vstride);
     float* a = val0;
     float* b = val1;
     for (int j = 0; j <= D; ++j) {
         // lattice points are a fraction of the worst case N (D + 1): a grid-stride launch sized for N / 4 points per channel
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * C)), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C);
+        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * C), nimg), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C, vstride);
         float* t = a; a = b; b = t;
     }
-    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm);
+    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((unsigned)((N + 255) / 256), nimg), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm,
+                       vstride, N * C);
 }
 
 template <int D>
@@ -404,17 +441,17 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)lt.cap * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, 1.0f / sxy, 1.0f / srgb, lt.hkeys,
                        (unsigned)(lt.cap - 1), lt.off, lt.bary, overflow);
-    hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((lt.cap + 4095) / 4096)), dim3(256), 0, s, lt.hkeys, lt.cap, lt.hid, lt.pkeys, lt.M);
+    hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((nv + 4095) / 4096)), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.M);
     hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
     hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, lt.hkeys, lt.hid,
                        (unsigned)(lt.cap - 1), lt.nb, lt.mmax);
-    (void)hipMemsetAsync(lt.cnt, 0, (size_t)(2 * nv) * sizeof(int), s);
-    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.cnt, nv);
+    (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
+    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.cnt, lt.cnt + nv, nv);
     hipLaunchKernelGGL(crf_alloc_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);
     hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.ent, lt.entw, nv, D + 1);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
-    crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, s);
-    crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, s);
+    crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, 1, s);
+    crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, 1, s);
 }
 
 // largest |lattice coordinate| the features can produce: |elevated_j| <= sum_i cf_i + j cf_j, cf_i = fmax_i * scale_i (Permutohedral::init)
@@ -437,7 +474,7 @@ extern "C" int64_t simseg_dense_crf_workspace_bytes(int64_t B, int64_t H, int64_
     CrfLattice lat[2];
     float *v0, *v1, *q1, *u, *fg, *fb;
     int* flags;
-    crf_carve(L, nullptr, B * H * W, (int)C, lat, v0, v1, q1, u, fg, fb, flags);
+    crf_carve(L, nullptr, B * H * W, H * W, (int)C, lat, v0, v1, q1, u, fg, fb, flags);
     return (int64_t)L.total + 256;
 }
 
@@ -469,15 +506,16 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     CrfLattice lat[2];
     float *val0, *val1, *q1, *u, *fg, *fb;
     int* flags;
-    crf_carve(L, static_cast<char*>(workspace), NT, Ci, lat, val0, val1, q1, u, fg, fb, flags);
+    crf_carve(L, static_cast<char*>(workspace), NT, N, Ci, lat, val0, val1, q1, u, fg, fb, flags);
     (void)hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
-    crf_build<2>(lat[0], rgb, (int)B, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
+    // the spatial lattice depends on (H, W, sxy) only: built for ONE image, shared by the batch
+    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
     crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, sxy_b, srgb, flags + 2, val0, val1, s);
     const long nc = NT * Ci;
     hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci);
     for (int it = 0; it < iters; ++it) {
-        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, NT, Ci, 0, s);
-        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, s);
+        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, (int)B, s);
+        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, 1, s);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
                            q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci);

@@ -1181,6 +1181,14 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (v == 1 && g_gemm_variant == 0 && !TA && !TB && splitk <= 1 && t128 >= 160 && t128 <= 256) v = 5;
+    if (v == 8 || v == 9) {      // experiments: 256x128 / 128x256 tiles, 4-wave blocks, two blocks per CU (one block's epilogue under the other's K loop)
+        if (aligned && p.K % 32 == 0 && p.M >= 256 && p.N >= 256) {
+            g_gemm_last_variant = v;
+            if (v == 8) return launch_large<TO, TA, TB, 32, 3, 256, 128, 2, 2, 2>(p, splitk, s);
+            return launch_large<TO, TA, TB, 32, 3, 128, 256, 2, 2, 2>(p, splitk, s);
+        }
+        v = 1;
+    }
     if (v == 5) {      // 128x128 tile on the direct-to-LDS ring (4 stages): mid-size problems, one block per CU
         if (aligned && p.K % 64 == 0 && p.M >= 128 && p.N >= 128) { g_gemm_last_variant = 5; return launch_large<TO, TA, TB, 64, 4, 128, 128, 2, 2, 1>(p, splitk, s); }
         v = 1;
