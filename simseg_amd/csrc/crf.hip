@@ -48,33 +48,71 @@ __device__ __forceinline__ unsigned crf_hash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return (unsigned)x;
 }
+// Two-tier open-addressing table.  The big table must hold the worst case (every (pixel, vertex) pair a distinct point: 2 x entries
+// slots, 512 MiB for a 16-image batch of 512^2), but a photograph's lattice has ~15 entries per point - and 25 M CAS operations
+// scattered over 512 MiB are DRAM-latency bound.  So keys go to a SMALL front table first (entries / 4 slots: resident in the memory-side
+// cache), probing at most CRF_PROBES slots there, and only spill into the big table when all of those are taken by other keys.  Nothing is
+// ever removed, so the protocol is consistent: a key is in the front table iff a free slot lay within its probe window when it was
+// inserted, and an EMPTY slot inside the window proves absence everywhere.  Slots are numbered front table first.
+constexpr int CRF_PROBES = 8;
+struct CrfTable { unsigned long long* keys; int* id; unsigned smask, bmask; };
+
 // returns the slot of `key`, with bit 31 set when THIS call created the entry (exactly one caller per lattice point does)
-__device__ __forceinline__ int crf_insert(unsigned long long* hkeys, unsigned mask, unsigned long long key) {
-    unsigned slot = crf_hash(key) & mask;
-    for (;;) {
-        const unsigned long long prev = atomicCAS(hkeys + slot, CRF_EMPTY, key);
+__device__ __forceinline__ int crf_insert(const CrfTable& t, unsigned long long key) {
+    const unsigned h = crf_hash(key);
+    unsigned slot = h & t.smask;
+#pragma unroll 1
+    for (int p = 0; p < CRF_PROBES; ++p) {
+        const unsigned long long prev = atomicCAS(t.keys + slot, CRF_EMPTY, key);
         if (prev == CRF_EMPTY) return (int)(slot | 0x80000000u);
         if (prev == key) return (int)slot;
-        slot = (slot + 1) & mask;
+        slot = (slot + 1) & t.smask;
+    }
+    const unsigned base = t.smask + 1;
+    slot = (h >> 3) & t.bmask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(t.keys + base + slot, CRF_EMPTY, key);
+        if (prev == CRF_EMPTY) return (int)((base + slot) | 0x80000000u);
+        if (prev == key) return (int)(base + slot);
+        slot = (slot + 1) & t.bmask;
     }
 }
-__device__ __forceinline__ int crf_find(const unsigned long long* hkeys, const int* hid, unsigned mask, unsigned long long key) {
-    unsigned slot = crf_hash(key) & mask;
-    for (;;) {
-        const unsigned long long cur = hkeys[slot];
-        if (cur == key) return hid[slot];
+__device__ __forceinline__ int crf_find(const CrfTable& t, unsigned long long key) {
+    const unsigned h = crf_hash(key);
+    unsigned slot = h & t.smask;
+#pragma unroll 1
+    for (int p = 0; p < CRF_PROBES; ++p) {
+        const unsigned long long cur = t.keys[slot];
+        if (cur == key) return t.id[slot];
         if (cur == CRF_EMPTY) return -1;
-        slot = (slot + 1) & mask;
+        slot = (slot + 1) & t.smask;
+    }
+    const unsigned base = t.smask + 1;
+    slot = (h >> 3) & t.bmask;
+    for (;;) {
+        const unsigned long long cur = t.keys[base + slot];
+        if (cur == key) return t.id[base + slot];
+        if (cur == CRF_EMPTY) return -1;
+        slot = (slot + 1) & t.bmask;
     }
 }
 
 // Permutohedral::init, one thread per pixel (pixel i = y * W + x).  D = 2: (x, y) / sxy;  D = 5: (x, y) / sxy, rgb / srgb.
 template <int D>
 __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int nimg, int H, int W, float inv_sxy, float inv_srgb,
-                                                          unsigned long long* __restrict__ hkeys, unsigned mask, int* __restrict__ off,
-                                                          float* __restrict__ bary, int* __restrict__ overflow) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // pixel of the batch: image i / (H W)
-    if (i >= (long)nimg * H * W) return;
+                                                          CrfTable table, int* __restrict__ off, float* __restrict__ bary,
+                                                          int* __restrict__ overflow) {
+    // Block-level de-duplication in front of the global table: neighbouring pixels share most of their simplex vertices (a lattice point
+    // has ~15 entries), and same-key CAS operations on one global address serialise.  The block's 256 x (D + 1) keys first meet in an LDS
+    // table; only the thread that creates a key THERE goes to the global table and publishes the slot for the others.
+    constexpr int LSLOTS = 2048;
+    __shared__ unsigned long long lkeys[LSLOTS];
+    __shared__ int lvals[LSLOTS];
+    for (int t = threadIdx.x; t < LSLOTS; t += 256) lkeys[t] = CRF_EMPTY;
+    __syncthreads();
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x;         // pixel of the batch: image i / (H W)
+    const bool valid = i0 < (long)nimg * H * W;
+    const long i = valid ? i0 : (long)nimg * H * W - 1;
     const int img = (int)(i / (H * W)), li = (int)(i % (H * W));
     float f[D];
     f[0] = (float)(li % W) * inv_sxy;
@@ -135,6 +173,7 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
     }
     bc[0] += 1.0f + bc[D + 1];
     bool bad = false;
+    int ls[D + 1];                                                // LDS slot of each vertex key, bit 31: this thread created it there
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
         int key[D];
@@ -143,10 +182,29 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
             key[k] = (int)rintf(rem0[k]) + (rank[k] <= D - r ? r : r - (D + 1));        // canonical simplex, remainder r
             bad = bad || key[k] < -(1 << (KeyBits<D>::B - 1)) || key[k] >= (1 << (KeyBits<D>::B - 1));
         }
-        off[(long)i * (D + 1) + r] = crf_insert(hkeys, mask, crf_pack<D>(key, img));  // hash slot (+ creator bit) for now; dense id after crf_assign
-        bary[(long)i * (D + 1) + r] = bc[r];
+        const unsigned long long pk = crf_pack<D>(key, img);
+        ls[r] = -1;
+        if (valid) {
+            unsigned slot = crf_hash(pk) & (LSLOTS - 1);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&lkeys[slot], CRF_EMPTY, pk);
+                if (prev == CRF_EMPTY) { lvals[slot] = crf_insert(table, pk); ls[r] = (int)(slot | 0x80000000u); break; }   // global slot (+ creator bit)
+                if (prev == pk) { ls[r] = (int)slot; break; }
+                slot = (slot + 1) & (LSLOTS - 1);
+            }
+        }
     }
-    if (bad) atomicExch(overflow, 1);
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r <= D; ++r) {
+            int g = lvals[ls[r] & 0x7fffffff];
+            if (ls[r] >= 0) g &= 0x7fffffff;                      // the creator bit stays with the one entry that created the point
+            off[(long)i * (D + 1) + r] = g;                       // hash slot (+ creator bit) for now; dense id after crf_assign
+            bary[(long)i * (D + 1) + r] = bc[r];
+        }
+    }
+    if (bad && valid) atomicExch(overflow, 1);
 }
 
 // Every lattice point draws a dense id, in the order of the (pixel, vertex) entries that CREATED the points (bit 31 of off[]): points
@@ -184,9 +242,39 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__
 // ---- the splat as a gather: per lattice point the list of (pixel, vertex) entries that touch it, built once per lattice
 // (count -> segment allocation -> fill), so that each of the ~10 filter applications of a CRF sums its values with plain loads
 // instead of 6 (d = 5) float atomics per pixel and channel (the atomic splat was 1.8 ms per filter of a 16-image batch)
+// rank[e] = position of entry e in its point's list, cnt[m] = list lengths.  A block's 1024 consecutive entries (~170 neighbouring
+// pixels) mostly repeat a few hundred points: they are counted in an LDS table first and each distinct point costs the block ONE global
+// atomicAdd (same-address global atomics serialise; this pass was 25 M of them).  The fill then needs no atomic at all.
 __global__ __launch_bounds__(256) void crf_count_kernel(const int* __restrict__ off, int* __restrict__ cnt, int* __restrict__ rank, long nv) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < nv) rank[e] = atomicAdd(cnt + off[e], 1);             // the entry's position in its point's list: the fill needs no second atomic
+    constexpr int LSLOTS = 2048, EPT = 4;
+    __shared__ int lid[LSLOTS], lcnt[LSLOTS], lbase[LSLOTS];
+    for (int t = threadIdx.x; t < LSLOTS; t += 256) { lid[t] = -1; lcnt[t] = 0; }
+    __syncthreads();
+    const long e0 = (long)blockIdx.x * (256 * EPT) + threadIdx.x;
+    int slot[EPT], lr[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const long e = e0 + 256 * j;
+        slot[j] = -1;
+        if (e < nv) {
+            const int m = off[e];
+            unsigned sl = ((unsigned)m * 0x9E3779B1u) >> 21;      // 11 bits
+            for (;;) {
+                const int prev = atomicCAS(&lid[sl], -1, m);
+                if (prev == -1 || prev == m) break;
+                sl = (sl + 1) & (LSLOTS - 1);
+            }
+            slot[j] = (int)sl;
+            lr[j] = atomicAdd(&lcnt[sl], 1);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < LSLOTS; t += 256)
+        if (lid[t] >= 0) lbase[t] = atomicAdd(cnt + lid[t], lcnt[t]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (slot[j] >= 0) rank[e0 + 256 * j] = lbase[slot[j]] + lr[j];
 }
 __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ cnt, int* __restrict__ start, const int* __restrict__ M,
                                                         int* __restrict__ cursor) {
@@ -232,7 +320,7 @@ __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict
         const int s0 = live ? start[m] : 0, n = live ? cnt[m] : 0;
         for (int j = sub; j < n; j += G) {
             const long px = ent[s0 + j];
-            const float w = entw[s0 + j] * (scale ? scale[px] : 1.0f);
+            const float w = entw[s0 + j];                         // (already times scale[px] when the filter's input is scaled: entws)
 #pragma unroll
             for (int c = 0; c < CRF_MAXC; ++c)
                 if (c < C) acc[c] += w * (in ? in[px * C + c] : 1.0f);
@@ -251,6 +339,14 @@ __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict
     }
 }
 
+// entws = entw * norm[pixel]: every filter of the mean field scales its input by the lattice's norm - folded into the list weights once,
+// so the gather makes one scattered read per entry (the value) instead of two
+__global__ __launch_bounds__(256) void crf_prescale_kernel(const int* __restrict__ ent, const float* __restrict__ entw, const float* __restrict__ norm,
+                                                           float* __restrict__ entws, long nv) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < nv) entws[e] = entw[e] * norm[ent[e]];
+}
+
 __global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off, const int* __restrict__ hid, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) off[i] = hid[off[i] & 0x7fffffff];
@@ -258,8 +354,7 @@ __global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off,
 
 template <int D>
 __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long long* __restrict__ pkeys, const int* __restrict__ M,
-                                                            const unsigned long long* __restrict__ hkeys, const int* __restrict__ hid,
-                                                            unsigned mask, int* __restrict__ nb, long mmax) {
+                                                            CrfTable table, int* __restrict__ nb, long mmax) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < *M; i += (long)gridDim.x * 256) {
         int key[D];
         const int img = crf_unpack<D>(pkeys[i], key);
@@ -269,8 +364,8 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long 
 #pragma unroll
             for (int k = 0; k < D; ++k) { k1[k] = key[k] - 1; k2[k] = key[k] + 1; }
             if (j < D) { k1[j] = key[j] + D; k2[j] = key[j] - D; }
-            nb[((long)j * mmax + i) * 2 + 0] = crf_find(hkeys, hid, mask, crf_pack<D>(k1, img));
-            nb[((long)j * mmax + i) * 2 + 1] = crf_find(hkeys, hid, mask, crf_pack<D>(k2, img));
+            nb[((long)j * mmax + i) * 2 + 0] = crf_find(table, crf_pack<D>(k1, img));
+            nb[((long)j * mmax + i) * 2 + 1] = crf_find(table, crf_pack<D>(k2, img));
         }
     }
 }
@@ -352,8 +447,8 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict
 
 struct CrfLattice {
     int* off; float* bary; unsigned long long* hkeys; int* hid; unsigned long long* pkeys; int* nb; float* norm; float* kn; int* M;
-    int* cnt; int* start; int* ent; float* entw; int* cursor;         // per-point entry lists: pixel and weight of every (pixel, vertex) pair
-    long cap, mmax;
+    int* cnt; int* start; int* ent; float* entw; float* entws; int* cursor;   // per-point entry lists: pixel, weight (and weight x norm[pixel]) of every (pixel, vertex) pair
+    long cap, scap, mmax;             // big / front table slots (hkeys, hid hold scap + cap entries)
 };
 
 struct CrfLayout {
@@ -380,11 +475,12 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
     for (int k = 0; k < 2; ++k) {
         const long nv = npx[k] * (dims[k] + 1);
         lat[k].cap = crf_cap(nv);
+        lat[k].scap = crf_cap(nv / 8);        // front table: entries / 4 slots
         lat[k].mmax = nv;
         lat[k].off = L.carve<int>(base, nv);
         lat[k].bary = L.carve<float>(base, nv);
-        lat[k].hkeys = L.carve<unsigned long long>(base, lat[k].cap);
-        lat[k].hid = L.carve<int>(base, lat[k].cap);
+        lat[k].hkeys = L.carve<unsigned long long>(base, lat[k].scap + lat[k].cap);
+        lat[k].hid = L.carve<int>(base, lat[k].scap + lat[k].cap);
         lat[k].pkeys = L.carve<unsigned long long>(base, nv);
         lat[k].nb = L.carve<int>(base, nv * (dims[k] + 1) * 2);
         lat[k].norm = L.carve<float>(base, npx[k]);
@@ -393,6 +489,7 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
         lat[k].start = L.carve<int>(base, nv);
         lat[k].ent = L.carve<int>(base, nv);
         lat[k].entw = L.carve<float>(base, nv);
+        lat[k].entws = L.carve<float>(base, nv);
     }
     const long vmax = (N * 6 + 1) * (long)C;
     val0 = L.carve<float>(base, vmax);
@@ -420,8 +517,8 @@ void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, co
     const long vstride = (N * (D + 1) + 1) * (long)C;
     (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
     (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);
-    hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent, lt.entw, val0, lt.M,
-                       C, N * C, vstride);
+    hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent,
+                       scale_in ? lt.entws : lt.entw, val0, lt.M, C, N * C, vstride);
     float* a = val0;
     float* b = val1;
     for (int j = 0; j <= D; ++j) {
@@ -438,19 +535,20 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
                hipStream_t s) {
     const long N = (long)nimg * H * W;
     const long nv = N * (D + 1);
-    (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)lt.cap * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, 1.0f / sxy, 1.0f / srgb, lt.hkeys,
-                       (unsigned)(lt.cap - 1), lt.off, lt.bary, overflow);
+    (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)(lt.scap + lt.cap) * sizeof(unsigned long long), s);
+    const CrfTable table{lt.hkeys, lt.hid, (unsigned)(lt.scap - 1), (unsigned)(lt.cap - 1)};
+    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, 1.0f / sxy, 1.0f / srgb, table,
+                       lt.off, lt.bary, overflow);
     hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((nv + 4095) / 4096)), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.M);
     hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
-    hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, lt.hkeys, lt.hid,
-                       (unsigned)(lt.cap - 1), lt.nb, lt.mmax);
+    hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, table, lt.nb, lt.mmax);
     (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
-    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.cnt, lt.cnt + nv, nv);
+    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.cnt, lt.cnt + nv, nv);
     hipLaunchKernelGGL(crf_alloc_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);
     hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.ent, lt.entw, nv, D + 1);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
     crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, 1, s);
+    hipLaunchKernelGGL(crf_prescale_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.ent, lt.entw, lt.norm, lt.entws, nv);
     crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, 1, s);
 }
 

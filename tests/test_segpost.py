@@ -276,6 +276,26 @@ def test_dense_crf_kernels_vs_oracle(H, W, cell, C):
 
 
 @pytest.mark.gpu
+def test_dense_crf_worst_case_lattice_spills_to_the_big_table():
+    """Pure colour noise: (almost) every (pixel, vertex) pair is its own lattice point - the case the big hash table is sized for.  The
+    front table (entries / 4 slots) fills up and keys spill into the big one; results must still equal the oracle's."""
+    from oracle import crf_ref as CR
+    from simseg_amd import ops
+    rng = np.random.default_rng(11)
+    H = W = 96
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    _, prob, _ = _crf_scene(H, W, 4, 16)
+    lat = CR.Permutohedral(CR.features_2d(H, W, 40.0, img, 13.0))
+    assert lat.M > 0.45 * H * W * 6 > 2 * (1 << 13)              # far more points than front-table slots (2^14 for these 55 296 entries)
+    mask, q = ops.dense_crf(torch.from_numpy(img).cuda(), torch.from_numpy(prob[None]).cuda(), want_q=True)
+    want, Qw = CR.dense_crf(img, prob, return_q=True)
+    agree = ((mask[0].cpu().numpy() > 0) == (want > 0)).mean()
+    dq = np.abs(q[0].cpu().numpy() - Qw[..., 1])
+    print(f"noise image: {lat.M} lattice points for {H * W * 6} entries; labels agree {agree:.5f}, |dQ| mean {dq.mean():.2e}")
+    assert agree >= 0.999 and dq.mean() < 2e-3
+
+
+@pytest.mark.gpu
 def test_dense_crf_batch_equals_per_image_calls():
     """The images of a batch are solved side by side in ONE set of lattices (the image index is part of the lattice key): every
     image's result equals its own single-image call, and the oracle."""
