@@ -221,7 +221,7 @@ def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monke
     (no per-forward concatenation); before that - and in evaluation - the concatenation is made once and reused.
     (b) The reference's AMP step `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`
     (simseg/core/hooks/optimizer.py:73-82) runs unmodified over this model + optimizer: with bf16 compute the scale is a power of
-    two and cancels, so the parameters after the step equal those of the unscaled step."""
+    two and cancels, so the unscaled gradients equal those of the plain step (to the rounding of the split-K atomics)."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
     from simseg_amd import towers
     from simseg_amd.optim import AdamW
@@ -239,20 +239,26 @@ def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monke
             m(batch)
         first = towers._wt_stacked(ws, torch.bfloat16)
         assert towers._wt_stacked(ws, torch.bfloat16) is first                      # evaluation: one concatenation, reused
-        for _ in range(2):
+        for it in range(2):
             opt.zero_grad(set_to_none=True)
             loss = m(batch)[0]["nce_loss"]
             scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            if it == 0:     # (compared on the gradients: AdamW's first steps are +-lr whatever the magnitude, so rounding-level noise on
+                            #  a near-zero gradient - split-K atomics order - flips whole updates)
+                results.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
             scaler.step(opt)
             scaler.update()
+        assert scaler.get_scale() == (65536.0 if use_scaler else 1.0)                  # no inf / nan step was skipped
         w3 = towers._wt_stacked(ws, torch.bfloat16)
         assert w3.data_ptr() == opt.state[sa.query.weight]["p16"].data_ptr() and w3.shape == (3 * ws[0].shape[0], ws[0].shape[1])
         assert torch.equal(w3[ws[0].shape[0]:2 * ws[0].shape[0]], sa.key.weight.detach().bfloat16())      # current values, in place
+        assert all(torch.isfinite(p).all() for p in m.parameters())
         torch.cuda.synchronize()
-        results.append({n: p.detach().clone() for n, p in m.named_parameters()})
-    worst = max(float((results[0][n] - results[1][n]).abs().max()) for n in results[0])
-    print("max parameter difference, GradScaler step vs plain step:", worst)
-    assert worst < 1e-6
+    worst = max(float((results[0][n] - results[1][n]).abs().max() / (results[0][n].abs().max() + 1e-30)) for n in results[0]
+                if "key.bias" not in n)
+    print("max gradient difference (relative to the tensor's max), GradScaler step vs plain step:", worst)
+    assert worst < 1e-4
 
 
 def test_full_size_vs_oracle(monkeypatch):
