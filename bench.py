@@ -303,21 +303,22 @@ def seg_latency_bench(dev, dtype, img, classes, tag, dim, reps=50):
 def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
     """BASELINE configs[4] shape: R@1/5/10 in both directions over the full 5k x 25k similarity matrix (fp32 MFMA GEMM +
     first-match-rank kernel instead of the reference's argsort + int64 gid gather, hooks/utils.py:36-42)."""
-    from simseg_amd.heads import retrieval_recalls
+    from simseg_amd.heads import retrieval_recalls_both
     g = torch.Generator().manual_seed(5)
     img = torch.nn.functional.normalize(torch.randn(m, d, generator=g), dim=-1).to(dev)
     txt = torch.nn.functional.normalize(img.repeat_interleave(n // m, 0) + 0.08 * torch.randn(n, d, generator=g).to(dev), dim=-1)
     gi, gt = torch.arange(m, device=dev), torch.arange(n, device=dev) // (n // m)
-    retrieval_recalls(img, gi, txt, gt)
+    retrieval_recalls_both(img, gi, txt, gt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        a = retrieval_recalls(img, gi, txt, gt)
-        b = retrieval_recalls(txt, gt, img, gi)
+        a, b = retrieval_recalls_both(img, gi, txt, gt)      # ONE similarity matrix: rows rank columns (i2t), columns rank rows (t2i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # "similarities" counts both directions' M x N scores as the reference's two calls produce them (2 M N), computed here once
     return {"shape": f"{m}x{n}x{d}, both directions", "ms_per_eval": round(dt * 1e3, 3), "similarities_per_s": round(2.0 * m * n / dt, 1),
-            "gemm_tflops_fp32": round(2 * 2.0 * m * n * d / dt / 1e12, 1), "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
+            "gemm_tflops_fp32": round(2.0 * m * n * d / dt / 1e12, 1), "gemm_launches_per_eval": 1,
+            "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
 
 
 def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250):
@@ -325,7 +326,7 @@ def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250
     288^2 and 25000 captions of 25 tokens through the towers (bf16), then recalls in both directions.  Synthetic inputs,
     random weights; returns wall time and rates."""
     from simseg.models import PIPELINE
-    from simseg_amd.heads import retrieval_recalls
+    from simseg_amd.heads import retrieval_recalls_both
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
     cfg, build = build_model("vit_base_patch16_224_in21k", 768, img)
     torch.manual_seed(11)
@@ -343,7 +344,7 @@ def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250
             ie, te = torch.cat(ie).float(), torch.cat(te).float()
             gi = torch.arange(ie.shape[0], device=dev)
             gt = torch.arange(te.shape[0], device=dev) // cap_per_img
-            return retrieval_recalls(ie, gi, te, gt), retrieval_recalls(te, gt, ie, gi)
+            return retrieval_recalls_both(ie, gi, te, gt)
 
     run()
     torch.cuda.synchronize()

@@ -142,6 +142,10 @@ int simseg_scale_by_scalar(const float* x, const float* scalar, float* y, int64_
  * argsort/gather/first-match rank of simseg/tasks/clip/hooks/utils.py:36-42,64-66 on tie-free scores. */
 int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, const int64_t* right_gid, int32_t* has_match, int32_t* rank,
                           int64_t M, int64_t N, int64_t ld, void* stream);
+/* The reverse direction from the SAME matrix: column j retrieves rows (best = max over rows with row_gid == col_gid[j], rank = rows
+ * scoring strictly higher) - two row-major passes instead of a second GEMM on swapped operands.  scratch: N int32. */
+int simseg_retrieval_rank_cols(const float* sim, const int64_t* row_gid, const int64_t* col_gid, int32_t* has_match, int32_t* rank,
+                               int32_t* scratch, int64_t M, int64_t N, int64_t ld, void* stream);
 /* counts4 = {#has_match, #rank<b0, #rank<b1, #rank<b2}  (hooks/utils.py:69-71). */
 int simseg_recall_counts(const int32_t* has_match, const int32_t* rank, int64_t M, int b0, int b1, int b2, int32_t* counts4,
                          void* stream);

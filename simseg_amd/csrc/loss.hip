@@ -149,6 +149,38 @@ __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __rest
     }
 }
 
+// The reverse direction from the SAME similarity matrix (columns retrieve rows): for column j, best = max_i{sim_ij : gid match},
+// rank = #{i : sim_ij > best}.  Two row-major passes over the matrix (thread per column, a block covers 256 columns x a band of rows;
+// per-column partial results meet in one atomic per block) instead of a second M x N GEMM on swapped operands.
+__device__ __forceinline__ int ord_f32(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float unord_f32(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__global__ __launch_bounds__(256) void retrieval_cols_init_kernel(int* __restrict__ best, int* __restrict__ rank, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < N) { best[j] = ord_f32(-INFINITY); rank[j] = 0; }
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void retrieval_cols_kernel(const float* __restrict__ sim, const long* __restrict__ rgid_rows,
+                                                             const long* __restrict__ cgid, int* __restrict__ best, int* __restrict__ has,
+                                                             int* __restrict__ rank, int M, int N, long ld, int band) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * band, r1 = min(M, r0 + band);
+    if (j >= N) return;
+    const float* col = sim + j;
+    if (PASS == 0) {
+        const long g = cgid[j];
+        float b = -INFINITY;
+        for (int r = r0; r < r1; ++r)
+            if (rgid_rows[r] == g) b = fmaxf(b, col[(long)r * ld]);
+        if (b > -INFINITY) atomicMax(best + j, ord_f32(b));
+    } else {
+        const float b = unord_f32(best[j]);
+        int cnt = 0;
+        for (int r = r0; r < r1; ++r) cnt += col[(long)r * ld] > b ? 1 : 0;
+        if (cnt) atomicAdd(rank + j, cnt);
+        if (blockIdx.y == 0) has[j] = b > -INFINITY ? 1 : 0;
+    }
+}
+
 // counts[0] = #rows with a match, counts[1..nb] = #rows with a match and rank < bound_b
 __global__ __launch_bounds__(256) void recall_count_kernel(const int* __restrict__ has, const int* __restrict__ rank, long M,
                                                            int b0, int b1, int b2, int* __restrict__ counts) {
@@ -258,6 +290,21 @@ extern "C" int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, 
     hipLaunchKernelGGL(retrieval_rank_kernel, dim3((unsigned)M), dim3(256), 0, STREAM, sim, (const long*)left_gid, (const long*)right_gid,
                        has_match, rank, (int)N, (long)ld);
     SS_LAUNCH_CHECK("retrieval_rank");
+    return 0;
+}
+
+extern "C" int simseg_retrieval_rank_cols(const float* sim, const int64_t* row_gid, const int64_t* col_gid, int32_t* has_match,
+                                          int32_t* rank, int32_t* scratch, int64_t M, int64_t N, int64_t ld, void* stream) {
+    SS_CHECK(sim && row_gid && col_gid && has_match && rank && scratch, "retrieval_rank_cols: null pointer");
+    if (N <= 0 || M <= 0) return 0;
+    const int band = 128;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + band - 1) / band));
+    hipLaunchKernelGGL(retrieval_cols_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, STREAM, scratch, rank, (int)N);
+    hipLaunchKernelGGL(retrieval_cols_kernel<0>, grid, dim3(256), 0, STREAM, sim, (const long*)row_gid, (const long*)col_gid, scratch, has_match, rank,
+                       (int)M, (int)N, (long)ld, band);
+    hipLaunchKernelGGL(retrieval_cols_kernel<1>, grid, dim3(256), 0, STREAM, sim, (const long*)row_gid, (const long*)col_gid, scratch, has_match, rank,
+                       (int)M, (int)N, (long)ld, band);
+    SS_LAUNCH_CHECK("retrieval_rank_cols");
     return 0;
 }
 

@@ -155,6 +155,22 @@ def retrieval_recalls(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
     return {f"R@{b}": float(c[i + 1]) / float(c[0]) for i, b in enumerate(bounds)}
 
 
+def retrieval_recalls_both(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
+    """Both directions of the retrieval evaluation (tools/retrieval_evaluation.py:33-40 calls the metric twice with swapped arguments)
+    from ONE similarity matrix: rows rank their columns, columns rank their rows.  Returns (left->right, right->left)."""
+    lg, rg = left_gid.contiguous().long(), right_gid.contiguous().long()
+    sim = ops.gemm(left.contiguous().float(), right.contiguous().float())
+    has, rank = ops.retrieval_rank(sim, lg, rg)
+    hasc, rankc = ops.retrieval_rank_cols(sim, lg, rg)
+    c = torch.stack([ops.recall_counts(has, rank, bounds), ops.recall_counts(hasc, rankc, bounds)]).cpu()
+    out = []
+    for d in range(2):
+        if int(c[d, 0]) == 0:
+            raise AssertionError("no row has a match in the other set")
+        out.append({f"R@{b}": float(c[d, i + 1]) / float(c[d, 0]) for i, b in enumerate(bounds)})
+    return out[0], out[1]
+
+
 @torch.no_grad()
 def class_text_embeddings(model, input_ids, attention_mask, chunk=2048):
     """Zero-shot classifier weights (tools/seg_evaluation.py:57-75) as batched calls: input_ids / attention_mask are

@@ -280,6 +280,17 @@ def retrieval_rank(sim, left_gid, right_gid):
     return has, rank
 
 
+def retrieval_rank_cols(sim, row_gid, col_gid):
+    """Column j of sim [M,N] retrieves rows: (has [N], rank [N]) from the same matrix the row direction used."""
+    require_gpu(sim)
+    M, N = sim.shape
+    has = torch.empty(N, device=sim.device, dtype=torch.int32)
+    rank = torch.empty(N, device=sim.device, dtype=torch.int32)
+    scratch = torch.empty(N, device=sim.device, dtype=torch.int32)
+    call("simseg_retrieval_rank_cols", ptr(_c(sim)), ptr(_c(row_gid)), ptr(_c(col_gid)), ptr(has), ptr(rank), ptr(scratch), M, N, N, stream())
+    return has, rank
+
+
 def recall_counts(has, rank, bounds=(1, 5, 10)):
     counts = torch.empty(4, device=has.device, dtype=torch.int32)
     call("simseg_recall_counts", ptr(has), ptr(rank), has.numel(), int(bounds[0]), int(bounds[1]), int(bounds[2]), ptr(counts), stream())

@@ -38,6 +38,17 @@ def test_retrieval_full_config5():
     r = rank[rows].long()
     assert bool(((r >= lo) & (r <= hi)).all())
     assert abs(t2i["R@1"] - float((rank == 0).float().mean())) < 1e-6
+    # both directions from ONE similarity matrix (columns rank their rows): the same recalls as the two single-direction calls,
+    # and column ranks of the [5000, 25000] matrix equal the row ranks of its transpose (same fp32 products, same comparisons)
+    from simseg_amd.heads import retrieval_recalls_both
+    a, b = retrieval_recalls_both(img, gi, txt, gt)
+    for k in ("R@1", "R@5", "R@10"):
+        assert abs(a[k] - i2t[k]) < 1e-9 and abs(b[k] - t2i[k]) < 2e-4, (k, a[k], i2t[k], b[k], t2i[k])
+    simT = ops.gemm(img, txt)
+    hasc, rankc = ops.retrieval_rank_cols(simT, gi, gt)
+    assert int(hasc.sum()) == 25000
+    rc = rankc[rows].long()
+    assert bool(((rc >= lo) & (rc <= hi)).all())
 
 
 def test_seg_similarity_full_config4():

@@ -590,6 +590,13 @@ def test_retrieval_rank(ops, golden):
         match = lg[:, None] == rg[None, :]
         best = torch.where(match, s, torch.full_like(s, -float("inf"))).max(1)[0]
         assert torch.equal(rank.long(), (s > best[:, None]).sum(1))
+        # the reverse direction from the same matrix: columns rank their rows; against the reference's recalls of the swapped call
+        hasc, rankc = ops.retrieval_rank_cols(sim, lg, rg)
+        cc = ops.recall_counts(hasc, rankc).cpu().numpy()
+        np.testing.assert_allclose(cc[1:] / cc[0], g["t2i" if key == "i2t" else "i2t"], atol=1e-7)
+        bestc = torch.where(match, s, torch.full_like(s, -float("inf"))).max(0)[0]
+        assert torch.equal(hasc.bool(), bestc > -float("inf"))
+        assert torch.equal(rankc.long()[hasc.bool()], (s > bestc[None, :]).sum(0)[hasc.bool()])
 
 
 def test_adamw_step(ops):
