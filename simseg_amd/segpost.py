@@ -19,13 +19,17 @@ from . import ops
 CRF_PARAMS = dict(sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3)        # tools/seg_evaluation.py:48-51
 
 
-def crf_masks(prob_up, cand_idx, images_u8, chunk=16, **params):
-    """prob_up [B,K,H,W] fp32 (x16 nearest-upsampled normalised maps), cand_idx [B,K] (-1 = slot not visited), images_u8 [B,H,W,3]
-    -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the reference loops on
-    the host per image and candidate); images with a visited candidate go through the device CRF `chunk` at a time (the lattices of
-    an image are shared by its candidates; images are grouped by their number of visited candidates)."""
-    B, K, H, W = prob_up.shape
-    masks = torch.zeros(B, K, H, W, device=prob_up.device, dtype=torch.uint8)
+def crf_masks(prob, cand_idx, images_u8, chunk=16, scale=1, **params):
+    """prob [B,K,h,w] fp32 normalised candidate maps (at 1/scale of the image resolution: the x16 nearest upsampling of the tool,
+    tools/seg_evaluation.py:141-143, is applied here per chunk and only to visited slots), cand_idx [B,K] (-1 = slot not visited),
+    images_u8 [B,H,W,3] -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the
+    reference loops on the host per image and candidate); images with a visited candidate go through the device CRF `chunk` at a time
+    (an image's candidates share its lattices; images are grouped by their number of visited candidates, so chunks carry few idle maps).
+    Per chunk: one gather of the visited low-resolution maps, one upsampling, one CRF call, one scatter of the masks."""
+    B, K, h, w = prob.shape
+    H, W = h * scale, w * scale
+    dev = prob.device
+    masks = torch.zeros(B, K, H, W, device=dev, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
     todo = [(b, visited[b].nonzero().flatten().tolist()) for b in range(B)]
@@ -33,13 +37,16 @@ def crf_masks(prob_up, cand_idx, images_u8, chunk=16, **params):
     for s in range(0, len(todo), chunk):
         part = todo[s:s + chunk]
         cmax = max(len(ks) for _, ks in part)
-        bs = [b for b, _ in part]
-        prob = torch.zeros(len(part), cmax, H, W, device=prob_up.device, dtype=torch.float32)
-        for j, (b, ks) in enumerate(part):
-            prob[j, :len(ks)] = prob_up[b, ks]
-        m, _ = ops.dense_crf(images_u8[bs].contiguous(), prob, **kw)
-        for j, (b, ks) in enumerate(part):
-            masks[b, ks] = m[j, :len(ks)]
+        slot = torch.full((len(part), cmax), -1, dtype=torch.int64)
+        for j, (_, ks) in enumerate(part):
+            slot[j, :len(ks)] = torch.tensor(ks)
+        valid = (slot >= 0).to(dev)
+        bsel = torch.tensor([b for b, _ in part], device=dev)
+        ksel = slot.clamp(min=0).to(dev)                           # idle slots repeat a visited map (their result is dropped)
+        lo = prob[bsel[:, None], ksel]                             # [n, cmax, h, w]
+        up = lo if scale == 1 else lo.repeat_interleave(scale, 2).repeat_interleave(scale, 3)
+        m, _ = ops.dense_crf(images_u8[bsel].contiguous(), up.contiguous(), **kw)
+        masks[bsel[:, None].expand(-1, cmax)[valid], ksel[valid]] = m[valid]
     return masks
 
 
@@ -54,11 +61,12 @@ def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand
     masks, prob = ops.seg_masks(sim, cand_idx, num_patch, want_prob=need_prob)
     if need_prob:
         B, K, N = prob.shape
-        up = prob.view(B, K, num_patch, num_patch).repeat_interleave(16, 2).repeat_interleave(16, 3)
+        lo = prob.view(B, K, num_patch, num_patch)
         if refine is not None:
+            up = lo.repeat_interleave(16, 2).repeat_interleave(16, 3)
             masks = refine(up, cand_idx, cand_score).to(torch.uint8).contiguous()
         else:
-            masks = crf_masks(up.contiguous(), cand_idx, images_u8)
+            masks = crf_masks(lo, cand_idx, images_u8, scale=16)
     if closing:
         masks = ops.close7(masks, cand_idx.reshape(-1))                       # cv2.dilate then cv2.erode (:156-157), visited slots only
     pred, hist = ops.seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index, hist=hist, want_pred=want_pred)

@@ -7,4 +7,4 @@ timeout 500 rocprofv3 --kernel-trace -d /tmp/crfprof -o p -- python $GRAFT_REPO_
 db=$(find /tmp/crfprof -name "*.db" 2>/dev/null | head -1)
 out=$GRAFT_REPO_ROOT/gpurun_out/${tag}.txt
 grep "windows_per_s" /tmp/crfprof.log > $out
-if [ -n "$db" ]; then timeout 120 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py "$db" 30 >> $out 2>&1; else tail -5 /tmp/crfprof.log >> $out; fi
+if [ -n "$db" ]; then timeout 120 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py "$db" 30 >> $out 2>&1; timeout 120 python $GRAFT_REPO_ROOT/tools/rocpd_gaps.py "$db" 0.0 >> $out 2>&1; else tail -5 /tmp/crfprof.log >> $out; fi
