@@ -103,6 +103,10 @@ int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float
  * whole head's K / V in LDS), 1 = always the streaming ring kernel, 4 = resident for every T <= 256 (2 / 3: timing ablations). */
 int simseg_set_attention_variant(int v);
 int simseg_debug_attn_occupancy(int64_t T);
+/* debug (thread-local): the ping-pong GEMM kernel writes 5 x uint64 per block into buf (wall-clock stamps at 100 MHz of block start, K loop
+ * start, K loop end, block end; HW_ID) - tools/dbg_gemm_trace.py; NULL switches it off. */
+int simseg_debug_gemm_trace(void* buf);
+int simseg_debug_gemm_stagger(int ticks);
 
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]

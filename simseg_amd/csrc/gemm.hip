@@ -51,6 +51,8 @@ struct GemmParams {
     int row_group;           // >0: output row r -> (r / G) * (G + 1) + 1 + r % G  (ViT token rows after [cls])
     int res_mod;             // residual row = 1 + r % G (pos_embed) instead of the output row
     int accumulate;          // C += result (fp32 output only; always set when split-K)
+    unsigned long long* dbg_trace;   // debugging only (simseg_debug_gemm_trace): per block {start, K loop start, K loop end, end} wall-clock stamps + hardware id
+    int stagger;             // ping-pong kernel: first-round blocks start (slot % 4) * stagger wall-clock ticks (10 ns) late (see launch_pp)
     int dbg_skip_epilogue;   // benchmarking only (simseg_set_gemm_variant(100 + v)): the accumulators are kept live but nothing is stored
     int ksplit;              // k-tiles per split-K slice
     int nsplit;              // number of split-K slices (grid = tiles * nsplit, slice-major so a slice's tiles share an XCD)
@@ -914,6 +916,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) mma<bf16_t>(acc[2 * (RH) + i_][CH], fa[i_ * 4 + kk_], FB[kk_]); \
     if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
 
+    if (p.stagger > 0 && blockIdx.x < 256) {                         // first round only: the phase offset then persists from round to round
+        const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (p.dbg_trace) tr0 = wall_clock64();
     // ---- prologue: half-tiles 0..PP_LEAD on their way, 0 and 1 landed, B half 0 of the first K-tile in registers
     PP_STAGE(0, 0) PP_STAGE(1, 1) PP_STAGE(2, 2) PP_STAGE(3, 3)
     if (PP_LEAD >= 4) PP_STAGE(4, 0)
@@ -924,6 +932,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     PP_READ_B(fb0, 0, 0)
     if (grp == 1) __builtin_amdgcn_s_barrier();                     // the second group runs one barrier behind the first
+    if (p.dbg_trace) tr1 = wall_clock64();
 
     // phase m = 4 * tile + q: reads half-tile m + 1, stages half-tile m + 1 + PP_LEAD and waits for half-tile m + 2 (the
     // PP_LEAD - 1 = 3 half-tiles staged after it may stay in flight)
@@ -962,21 +971,157 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #undef PP_CLUSTER
     wait_vm<0>();                                                    // (dummy copies of the tail)
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // both groups have left the last phase: the ring is free
+    if (p.dbg_trace) tr2 = wall_clock64();
 
     const bool atomic = p.nsplit > 1;
     const bool vec_ok = epilogue_vec_ok(p, sizeof(TO));
     float* wlds = reinterpret_cast<float*>(lds) + wave * EP_WAVE_FLOATS;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int c0 = n0 + wn * 32, c1 = c0 + 128;
+    if constexpr (sizeof(TO) == 2) {
+        // bf16 output without a per-element loaded operand (qkv / fc1 forward, the plain dgrads - most of the step's GEMM launches):
+        // the general epilogue below costs ~500 VALU / LDS instructions per wave and 32x64 block (fp32 staging, one ds_write_b32 per
+        // element, row-major re-read, conversion) - 8-9 us of a 28 us K = 768 tile on the per-block timeline.  Here bias / GELU run
+        // on the accumulators in MFMA layout (a lane owns ONE column: the bias is a scalar per lane), pairs of rows are packed to
+        // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
+        // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
+        const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && !p.aux && p.row_group == 0 && !p.drop_thresh && !p.colsum &&
+                            !p.dbg_skip_epilogue && (p.act == 0 || p.act == 1 || p.act == 3) && m0 + 256 <= p.M && n0 + 256 <= p.N;
+        if (fastep) {
+            constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
+            char* tl = reinterpret_cast<char*>(wlds);
+            const int cl = lane & 31, h2 = lane >> 5, g4 = lane >> 4, a16 = lane & 15;
+            const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+            bf16_t* Xb = reinterpret_cast<bf16_t*>(p.aux_out);
+            typedef s16x4 __attribute__((address_space(3))) * lptr;
+            auto emit = [&](const f32x16& xl, const f32x16& xr, bf16_t* dst, int row0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    union { bf16_t h[4]; uint2 u; } pl, pr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pl.h[e] = (bf16_t)xl[4 * q + e]; pr.h[e] = (bf16_t)xr[4 * q + e]; }
+                    *reinterpret_cast<uint2*>(tl + cl * TP + (8 * q + 4 * h2) * 2) = pl.u;
+                    *reinterpret_cast<uint2*>(tl + (32 + cl) * TP + (8 * q + 4 * h2) * 2) = pr.u;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int trow = (g4 & 1) * 16 + a16;
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int o = (g4 >> 1) + 2 * sidx;             // column octet of the staged 64: 0-3 left fragment, 4-7 right
+                    const char* src = tl + (o * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
+                    union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
+                    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
+                    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 4 * TP));
+                    const int col = o < 4 ? c0 + o * 8 : c1 + (o - 4) * 8;
+                    *reinterpret_cast<u32x4*>(dst + (long)(row0 + trow) * p.ldc + col) = u.v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x16 l, r;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { l[e] = acc[i][0][e] * p.alpha + bL; r[e] = acc[i][1][e] * p.alpha + bR; }
+                    emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+                }
+            } else
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                f32x16 l = acc[0][0], r = acc[0][1];
+#pragma unroll
+                for (int ii = 1; ii < 4; ++ii)
+                    if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
+                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+                f32x16 dl, dr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float vl = l[e] * p.alpha + bL, vr = r[e] * p.alpha + bR;
+                    dl[e] = vl; dr[e] = vr;                          // act 1: the saved pre-activation
+                    if (p.act == 1) { vl = gelu_erf(vl); vr = gelu_erf(vr); }
+                    else if (p.act == 3) { float d0, d1; vl = gelu_erf_grad(vl, d0); vr = gelu_erf_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
+                    l[e] = vl; r[e] = vr;
+                }
+                emit(l, r, Cb, row0);
+                if (p.act != 0 && Xb) emit(dl, dr, Xb, row0);
+            }
+            if (p.dbg_trace && tid == 0) {
+                const unsigned long long tr3 = wall_clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned long long* d = p.dbg_trace + (long)blockIdx.x * 5;
+                d[0] = tr0; d[1] = tr1; d[2] = tr2; d[3] = wall_clock64(); d[4] = tr3;
+            }
+            return;
+        }
+    }
+    if constexpr (sizeof(TO) == 4) {
+        // fp32 output (proj / fc2 forward: bias + dropout + fp32 residual): in the MFMA layout a lane owns one column and a store
+        // instruction covers 32 consecutive floats of a row per half-wave - whole 128-byte lines - so the accumulators are finished and
+        // stored where they are, the residual is loaded the same way, and nothing goes through LDS (the staged path: ~30 us of epilogue
+        // per K = 768 tile for 256 KB read + 256 KB written).  Residual loads of fragment pair i + 1 are requested before the stores of
+        // pair i, so no wait sits between a load and the stores ahead of it.
+        const bool direct = !atomic && !p.rowscale && !p.aux && p.act == 0 && p.row_group == 0 && !p.colsum && !p.accumulate &&
+                            !p.dbg_skip_epilogue && m0 + 256 <= p.M && n0 + 256 <= p.N;
+        if (direct) {
+            const int cl = lane & 31, h2 = lane >> 5;
+            const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
+            float* Cf = reinterpret_cast<float*>(p.C);
+            f32x16 rl[2], rr[2];                                     // residual of the current / next fragment pair
+            auto load_res = [&](int i, f32x16& xl, f32x16& xr) {
+                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long ro = (long)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h2) * p.ldr;
+                    xl[e] = p.residual[ro + c0 + cl];
+                    xr[e] = p.residual[ro + c1 + cl];
+                }
+            };
+            if (p.residual) load_res(0, rl[0], rr[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (p.residual && i < 3) load_res(i + 1, rl[(i + 1) & 1], rr[(i + 1) & 1]);
+                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+                    float vl = acc[i][0][e] * p.alpha + bL, vr = acc[i][1][e] * p.alpha + bR;
+                    if (p.drop_thresh) {
+                        vl = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c0 + cl, p.drop_thresh) ? vl * p.drop_scale : 0.f;
+                        vr = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c1 + cl, p.drop_thresh) ? vr * p.drop_scale : 0.f;
+                    }
+                    if (p.residual) { vl += rl[i & 1][e]; vr += rr[i & 1][e]; }
+                    Cf[(long)row * p.ldc + c0 + cl] = vl;
+                    Cf[(long)row * p.ldc + c1 + cl] = vr;
+                }
+            }
+            if (p.dbg_trace && tid == 0) {
+                const unsigned long long tr3 = wall_clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned long long* d = p.dbg_trace + (long)blockIdx.x * 5;
+                d[0] = tr0; d[1] = tr1; d[2] = tr2; d[3] = wall_clock64(); d[4] = tr3;
+            }
+            return;
+        }
+    }
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {                                   // rolled: one copy of the (large) epilogue body
         f32x16 l = acc[0][0], r = acc[0][1];
 #pragma unroll
         for (int ii = 1; ii < 4; ++ii)
             if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
+        if (p.dbg_trace && tid == 0) p.dbg_trace[(long)gridDim.x * 5 + (long)blockIdx.x * 4 + i] = wall_clock64();
         epilogue_block<TO>(p, l, r, wlds, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32, c0, c1, lane, atomic, vec_ok, cs);
     }
     flush_colsum(p, cs, c0, c1, lane);
+    if (p.dbg_trace && tid == 0) {
+        const unsigned long long tr3 = wall_clock64();               // every store of this wave is issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... and acknowledged
+        unsigned long long* d = p.dbg_trace + (long)blockIdx.x * 5;
+        d[0] = tr0; d[1] = tr1; d[2] = tr2; d[3] = wall_clock64(); d[4] = tr3;
+    }
 }
 
 template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1>
@@ -1006,6 +1151,8 @@ int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
 // Debug / benchmarking selectors.  Thread-local: the entry points are otherwise stateless and re-entrant, and a selector set by a
 // benchmark thread never changes what another caller's simseg_gemm launches.
 thread_local int g_gemm_debug_skip_epilogue = 0;
+thread_local unsigned long long* g_gemm_debug_trace = nullptr;
+thread_local int g_gemm_stagger = 0;
 thread_local int g_gemm_last_variant = 0;      // 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS, 3 = 256x256 ping-pong
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
@@ -1206,6 +1353,10 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
 // 3 = 256x256 ping-pong, 4 = small-problem kernel (the measurement code labels its per-kernel timings with this instead of re-deriving the dispatch rule)
 extern "C" int simseg_gemm_last_variant(void) { return g_gemm_last_variant; }
 
+// debugging: the ping-pong kernel writes 5 x u64 per block (start / K loop start / K loop end / end wall-clock stamps at 100 MHz, HW_ID)
+extern "C" int simseg_debug_gemm_stagger(int ticks) { g_gemm_stagger = ticks; return 0; }
+extern "C" int simseg_debug_gemm_trace(void* buf) { g_gemm_debug_trace = static_cast<unsigned long long*>(buf); return 0; }
+
 extern "C" int simseg_set_gemm_variant(int v) {
     g_gemm_debug_skip_epilogue = v >= 100;
     g_gemm_variant = v % 100;
@@ -1257,7 +1408,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.A = A; p.B = B; p.C = C; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.bias = bias; p.rowscale = rowscale;
     p.residual = residual; p.ldr = ldr; p.act = act; p.aux = aux; p.aux_out = aux_out;
-    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = accumulate; p.dbg_skip_epilogue = g_gemm_debug_skip_epilogue;
+    p.row_group = row_group; p.res_mod = res_mod; p.accumulate = accumulate; p.dbg_skip_epilogue = g_gemm_debug_skip_epilogue; p.dbg_trace = g_gemm_debug_trace; p.stagger = g_gemm_stagger;
     p.drop_seed = drop_seed;
     p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;

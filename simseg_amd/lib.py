@@ -8,7 +8,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "simseg_hip.h")
-LIB_PATH = os.path.join(HERE, "libsimseg_hip.so")
+LIB_PATH = os.environ.get("SIMSEG_AMD_LIB") or os.path.join(HERE, "libsimseg_hip.so")      # (override: same-box A/B runs of two builds)
 
 _CT = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float}
 
@@ -45,7 +45,11 @@ def load():
                 "simseg_amd has no CPU or eager-PyTorch fallback.")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in parse_header().items():
-            fn = getattr(lib, name)       # AttributeError here == header/library mismatch
+            fn = getattr(lib, name, None)
+            if fn is None:
+                if name.startswith("simseg_debug_"):     # an older build in an A/B run may lack a debug hook
+                    continue
+                raise AttributeError(f"{LIB_PATH} does not export {name}: header / library mismatch")
             fn.restype = ret
             fn.argtypes = [a for a, _ in args]
         _lib = lib
