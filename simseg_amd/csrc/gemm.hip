@@ -985,8 +985,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         // on the accumulators in MFMA layout (a lane owns ONE column: the bias is a scalar per lane), pairs of rows are packed to
         // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
         // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
-        const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && !p.aux && p.row_group == 0 && !p.drop_thresh && !p.colsum &&
-                            !p.dbg_skip_epilogue && (p.act == 0 || p.act == 1 || p.act == 3) && m0 + 256 <= p.M && n0 + 256 <= p.N;
+        const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && p.row_group == 0 && !p.drop_thresh && !p.dbg_skip_epilogue &&
+                            (p.act == 0 || p.act == 1 || p.act == 3 || (p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
+                            m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
             constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
             char* tl = reinterpret_cast<char*>(wlds);
@@ -1006,21 +1007,69 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int trow = (g4 & 1) * 16 + a16;
+                // this lane's four 8-column groups of its row: columns c0 + 8 (g4 >> 1) + {0, 16, 128, 144} (c1 = c0 + 128): one
+                // address, immediate offsets
+                bf16_t* drow = dst + (long)(row0 + (g4 & 1) * 16 + a16) * p.ldc + c0 + (g4 >> 1) * 8;
+                const char* src0 = tl + ((g4 >> 1) * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int o = (g4 >> 1) + 2 * sidx;             // column octet of the staged 64: 0-3 left fragment, 4-7 right
-                    const char* src = tl + (o * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
+                    const char* src = src0 + sidx * 16 * TP;         // staged column octet (g4 >> 1) + 2 sidx: 0-3 left fragment, 4-7 right
                     union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
                     u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
                     u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 4 * TP));
-                    const int col = o < 4 ? c0 + o * 8 : c1 + (o - 4) * 8;
-                    *reinterpret_cast<u32x4*>(dst + (long)(row0 + trow) * p.ldc + col) = u.v;
+                    *reinterpret_cast<u32x4*>(drow + (sidx & 1) * 16 + (sidx >> 1) * 128) = u.v;
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
-            if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
+            if (p.act == 4) {
+                // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major
+                // like the output: it takes the reverse trip - 16-byte row-major loads, staged [row][column], and ds_read_b64_tr_b16
+                // hands lane (column c) the 4 consecutive rows of each accumulator register group.  The loads of block i + 1 are
+                // requested before the stores of block i.
+                constexpr int PA = 144;                              // bytes per staged row (64 columns x 2 B + 16 B pad)
+                const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux);
+                const int trow = (g4 & 1) * 16 + a16;
+                const bf16_t* arow = Ab + (long)(m0 + grp * 64 + trow) * p.ldc + c0 + (g4 >> 1) * 8;
+                u32x4 ax[2][4];
+                auto load_aux = [&](int i, u32x4 (&dst)[4]) {
+                    const bf16_t* a_i = arow + (long)((i >> 1) * 128 + (i & 1) * 32) * p.ldc;
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) dst[sidx] = *reinterpret_cast<const u32x4*>(a_i + (sidx & 1) * 16 + (sidx >> 1) * 128);
+                };
+                load_aux(0, ax[0]);
+                float sL = 0.f, sR = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < 3) load_aux(i + 1, ax[(i + 1) & 1]);
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        *reinterpret_cast<u32x4*>(tl + trow * PA + ((g4 >> 1) + 2 * sidx) * 16) = ax[i & 1][sidx];
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    f32x16 l, r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const char* src = tl + (8 * q + 4 * h2 + (a16 >> 2)) * PA + (((cl >> 4) * 16) + (a16 & 3) * 4) * 2;
+                        const s16x4 tL = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
+                        const s16x4 tR = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 64));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float al = __uint_as_float((unsigned)(unsigned short)tL[e] << 16), ar = __uint_as_float((unsigned)(unsigned short)tR[e] << 16);
+                            l[4 * q + e] = (acc[i][0][4 * q + e] * p.alpha + bL) * al;
+                            r[4 * q + e] = (acc[i][1][4 * q + e] * p.alpha + bR) * ar;
+                            sL += l[4 * q + e]; sR += r[4 * q + e];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+                }
+                if (p.colsum) {
+                    sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
+                    if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
+                }
+            } else if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x16 l, r;
