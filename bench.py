@@ -357,6 +357,42 @@ def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250
             "images_per_s": round(n_img / dt, 1), "captions_per_s": round(n_img * cap_per_img / dt, 1)}
 
 
+class ClockSampler:
+    """Shader clock and package power during the timed region (rocm-smi polled from a side thread; host-side only).  MI355X is
+    power-capped under matrix-core load: the dense peaks of MI355X_MICROARCH.md assume 2.4 GHz, the step runs at ~1.9 GHz / ~1.36 kW,
+    a long-K GEMM alone at ~1.7 GHz / 1.4 kW (profiles/r2_clock_power_under_load.txt)."""
+
+    def __init__(self, period=0.3):
+        import threading
+        self.samples, self._stop, self.period = [], False, period
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+                w = re.search(r"Power \(W\): ([0-9.]+)", out)
+                if m and w:
+                    self.samples.append((int(m.group(1)), float(w.group(1))))
+            except Exception:       # noqa: BLE001  (no rocm-smi: the fields stay null)
+                return
+            time.sleep(self.period)
+
+    def stop(self):
+        self._stop = True
+        self.th.join(timeout=15)
+        s = self.samples[1:] if len(self.samples) > 2 else self.samples       # (the first sample may predate the load)
+        if not s:
+            return None
+        sclk = sum(x[0] for x in s) / len(s)
+        return {"sclk_mhz_avg": round(sclk, 0), "power_w_avg": round(sum(x[1] for x in s) / len(s), 0), "samples": len(s),
+                "nominal_sclk_mhz": 2400, "dense_bf16_peak_at_this_clock_tflops": round(PEAK_BF16 / 1e12 * sclk / 2400.0, 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,6 +468,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clocks = ClockSampler() if rank == 0 else None      # rocm-smi from a side thread: the chip is power-capped under this load
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -439,6 +476,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    clock_info = clocks.stop() if clocks is not None else None
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
@@ -530,7 +568,10 @@ def main():
                          "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
                          "flops_per_launch_avg": fl / cnt,
                          "measured": "one instrumented step with both towers on one stream (each launch alone on the GPU); the timed "
-                                     "steps overlap the two towers on two streams" if two_streams else "one instrumented step"},
+                                     "steps overlap the two towers on two streams" if two_streams else "one instrumented step",
+                         "clocks_during_timed_steps": clock_info,
+                         "frac_of_peak_at_measured_clock": (round(achieved / clock_info["dense_bf16_peak_at_this_clock_tflops"], 4)
+                                                            if clock_info else None)},
             "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),
                            "whole_step_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
                            "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
