@@ -67,9 +67,9 @@ int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* 
                          const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
                          float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p,
                          void* stream);
-/* Size (in floats) of the `partials` scratch of simseg_layernorm_bwd: per-block column sums, folded by a second small kernel
+/* Bytes of the `partials` workspace of simseg_layernorm_bwd: per-block column sums, folded by a second small kernel
  * (one add per column) instead of one atomic per column per block.  partials = NULL selects the atomic path. */
-int64_t simseg_layernorm_bwd_partials(int64_t rows, int64_t D);
+int64_t simseg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
 
 /* out[n] += sum_r in[r,n]  (bias / embedding-table gradients). */
 int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream);
@@ -93,9 +93,9 @@ int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, const float* 
  * pooled vector itself (TopKPooling used on its own). */
 int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
                                 float* scratch, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
-/* floats of the optional `scratch`: with it the tokens of an image are scanned by 32 blocks in parallel and merged (same
+/* bytes of the optional `scratch` workspace: with it the tokens of an image are scanned by 32 blocks in parallel and merged (same
  * result, ties included) - for small batches, where one block per image leaves the GPU empty; NULL = one block per image. */
-int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k);
+int64_t simseg_topk_pool_workspace_bytes(int64_t B, int64_t P, int k);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 

@@ -615,7 +615,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
 }
 
 /* floats the caller must provide as `partials` for a launch over `rows` rows of width D */
-extern "C" int64_t simseg_layernorm_bwd_partials(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, 1024) * 3 * D; }
+extern "C" int64_t simseg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, 1024) * 3 * D * (int64_t)sizeof(float); }
 
 extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream) {
     SS_CHECK(in && out, "colsum: null pointer");
@@ -685,7 +685,7 @@ extern "C" int simseg_bert_embed_bwd(const int64_t* ids, const int64_t* mask, co
     return 0;
 }
 
-extern "C" int64_t simseg_topk_pool_scratch(int64_t B, int64_t P, int k) { return B * (POOL_SLICES + POOL_GROUPS) * k * P * 2; }
+extern "C" int64_t simseg_topk_pool_workspace_bytes(int64_t B, int64_t P, int k) { return B * (POOL_SLICES + POOL_GROUPS) * k * P * 2 * (int64_t)sizeof(float); }
 
 extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
                                            float* scratch, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize,

@@ -104,7 +104,7 @@ def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dre
     rows = x.numel() // D
     dx32 = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_f32 else None
     dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
-    partials = torch.empty(raw("simseg_layernorm_bwd_partials", rows, D), device=x.device, dtype=torch.float32)
+    partials = torch.empty(raw("simseg_layernorm_bwd_workspace_bytes", rows, D) // 4, device=x.device, dtype=torch.float32)
     call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
          ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(partials), rows, D, int(drop_seed), float(drop_p), stream())
     return dx32, dx16
@@ -158,7 +158,7 @@ def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8, normalize=True):
     norm = torch.empty(B, device=tok.device, dtype=torch.float32)
     scratch = None
     if B < 64 and N >= 256:          # few images: scan token slices in parallel (one block per image would leave the GPU empty)
-        scratch = torch.empty(raw("simseg_topk_pool_scratch", B, P, int(k)), device=tok.device, dtype=torch.float32)
+        scratch = torch.empty(raw("simseg_topk_pool_workspace_bytes", B, P, int(k)) // 4, device=tok.device, dtype=torch.float32)
     call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), ptr(scratch), B, N, P, int(k),
          float(eps), int(normalize), stream())
     return emb, idx, norm

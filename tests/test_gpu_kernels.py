@@ -328,7 +328,7 @@ def test_topk_pool_sliced_equals_single_pass(ops):
         outs = []
         for sliced in (False, True):
             emb = torch.empty(B, P, device="cuda"); idx = torch.empty(B, k, P, device="cuda", dtype=torch.int32); norm = torch.empty(B, device="cuda")
-            scratch = torch.empty(raw("simseg_topk_pool_scratch", B, P, k), device="cuda") if sliced else None
+            scratch = torch.empty(raw("simseg_topk_pool_workspace_bytes", B, P, k) // 4, device="cuda") if sliced else None
             call("simseg_topk_pool_l2norm_fwd", ptr(tok), 0 if dtype == torch.float32 else 1, None, ptr(emb), ptr(idx), ptr(norm), ptr(scratch),
                  B, N, P, k, 1e-8, 1, stream())
             outs.append((emb, idx, norm))
