@@ -99,8 +99,8 @@ int64_t simseg_topk_pool_workspace_bytes(int64_t B, int64_t P, int k);
 int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                 int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream);
 
-/* Kernel selection for benchmarking / tests (thread-local): 0 auto (bf16 sequences of <= 128 tokens run the "resident" forward kernel that holds a
- * whole head's K / V in LDS), 1 = always the streaming ring kernel, 4 = resident for every T <= 256 (2 / 3: timing ablations). */
+/* Kernel selection for benchmarking / tests (thread-local): 0 auto (bf16 sequences of <= 256 tokens run the "resident" kernels that hold a
+ * whole head's K / V - or Q / dO - in LDS), 1 = always the streaming ring kernels (2 / 3: timing ablations). */
 int simseg_set_attention_variant(int v);
 int simseg_debug_attn_occupancy(int64_t T);
 /* debug (thread-local): the ping-pong GEMM kernel writes 5 x uint64 per block into buf (wall-clock stamps at 100 MHz of block start, K loop

@@ -709,7 +709,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // tile and ~660 cycles per tile in wait + barrier: profiles/r1_attn_timeline.txt.)
 // ------------------------------------------------------------------------------------------------
 constexpr int RES_MAXT = 256;
-constexpr int RES_AUTO_T = 128;          // measured (tools/dbg_attn_res.py): resident 56 vs ring 61 us at T=77, 20 vs 31 at T=25, 214 vs 209 at T=197
+constexpr int RES_AUTO_T = 256;          // measured (tools/dbg_attn_res.py): resident 56 vs ring 61 us at T=77, 20 vs 31 at T=25; at T=197 a tie in
+                                         // isolation (214 vs 209 us) and -0.3 ms per training step (same-box A/B), so resident wherever it fits
 
 // LDS of the resident kernels: [K rows8 x 128 B][V rows8 x 128 B][key bias], rows8 = T rounded up to 8 (rows T..rows8-1 repeat row
 // T-1).  Row r of K holds its eight 16-byte chunks at slots c ^ k_swz(r), V at c ^ v_swz(r) (the images the ring kernel's fragment

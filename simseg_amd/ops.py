@@ -1,5 +1,6 @@
 """Tensor-level wrappers over the C ABI (include/simseg_hip.h).  PyTorch supplies device memory and the stream;
 all arithmetic runs in libsimseg_hip.so.  No autograd here (see autograd.py) and no CPU fallback."""
+import os
 import threading
 
 import torch
@@ -25,7 +26,7 @@ def _c(t):
 
 # The library's kernel selectors are thread-local (include/simseg_hip.h: the compute entry points are re-entrant), and autograd runs
 # backward on its own threads: the selection made here is kept in Python and pushed to whichever thread launches next.
-_VARIANT = {"gemm": 0, "attention": 0}
+_VARIANT = {"gemm": int(os.environ.get("SIMSEG_GEMM_VARIANT", "0")), "attention": int(os.environ.get("SIMSEG_ATTN_VARIANT", "0"))}     # (env: A/B runs)
 _PUSHED = threading.local()
 
 
