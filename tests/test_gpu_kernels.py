@@ -164,6 +164,55 @@ def test_gemm_bf16_large_tile_kernel(ops, variant, ta, tb, M, N, K):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 768), (1024, 768, 128)])
+def test_gemm_pingpong_accumulator_layout_epilogues(ops, tb, M, N, K):
+    """Full 256x256 tiles on the ping-pong kernel finish in the accumulator layout (bf16: transposed staging + ds_read_b64_tr_b16;
+    fp32 + residual: direct row-segment stores).  Every such configuration against fp64 torch AND against the staged epilogue of the
+    128x128 kernel (same hash -> same dropout mask)."""
+    from simseg_amd.lib import raw
+    a = _rand(M, K, seed=1, dtype=torch.bfloat16)
+    b = _rand(*((K, N) if tb else (N, K)), seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    ref = (a.double() @ (b.double() if tb else b.double().T)).float()
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    aux = _rand(M, N, seed=5, dtype=torch.bfloat16)
+    x = (ref + bias).requires_grad_(True)
+    F.gelu(x).backward(torch.ones_like(x))
+    results = {}
+    for variant in (3, 1):
+        ops.set_gemm_variant(variant)
+        try:
+            r = {}
+            r["plain"] = ops.gemm(a, b, trans_b=tb)
+            assert raw("simseg_gemm_last_variant") == variant
+            r["bias_alpha"] = ops.gemm(a, b, trans_b=tb, bias=bias, alpha=0.5)
+            pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            r["gelu"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=1, aux_out=pre)
+            r["gelu_pre"] = pre
+            d = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            r["gelu3"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=3, aux_out=d)
+            r["gelu3_d"] = d
+            r["gelu3_noaux"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=3)
+            cs = torch.zeros(N, device="cuda")
+            r["times_aux"] = ops.gemm(a, b, trans_b=tb, act=4, aux=aux, colsum=cs)
+            r["times_aux_colsum"] = cs
+            r["f32_res"] = ops.gemm(a, b, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32)
+            r["f32_res_drop"] = ops.gemm(a, b, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32, drop_seed=7, drop_p=0.1)
+            results[variant] = r
+        finally:
+            ops.set_gemm_variant(0)
+    want = {"plain": ref, "bias_alpha": ref * 0.5 + bias, "gelu": F.gelu(ref + bias), "gelu_pre": ref + bias, "gelu3": F.gelu(ref + bias),
+            "gelu3_d": x.grad, "gelu3_noaux": F.gelu(ref + bias), "times_aux": ref * aux.float(), "f32_res": ref + bias + res}
+    for k, w in want.items():
+        _close(results[3][k], w, 1e-5 if k.startswith("f32") else 1e-2, f"ping-pong {k}")
+    _close(results[3]["times_aux_colsum"], (ref * aux.float()).sum(0), 2e-4, "column sums in the accumulator layout")
+    for k in results[3]:
+        tol = 1e-5 if k.startswith("f32") else (2e-4 if k.endswith("colsum") else 1e-2)
+        _close(results[3][k], results[1][k].float(), tol, f"ping-pong vs staged epilogue: {k}")
+    d3, d1 = results[3]["f32_res_drop"] - res, results[1]["f32_res_drop"] - res
+    assert float(((d3.abs() < 1e-6) != (d1.abs() < 1e-6)).float().mean()) < 1e-3          # the same dropout mask
+
+
 def test_gemm_bf16_splitk_and_dgelu(ops):
     K, M, N = 5000, 256, 384          # wgrad shape: contraction over rows
     dy, x = _rand(K, M, seed=1, dtype=torch.bfloat16), _rand(K, N, seed=2, dtype=torch.bfloat16)
