@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                 for (int e = 0; e < 16; ++e) {
                     float vl = l[e] * p.alpha + bL, vr = r[e] * p.alpha + bR;
                     dl[e] = vl; dr[e] = vr;                          // act 1: the saved pre-activation
-                    if (p.act == 1) { vl = gelu_erf(vl); vr = gelu_erf(vr); }
-                    else if (p.act == 3) { float d0, d1; vl = gelu_erf_grad(vl, d0); vr = gelu_erf_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
+                    if (p.act == 1) { vl = gelu_poly(vl); vr = gelu_poly(vr); }
+                    else if (p.act == 3) { float d0, d1; vl = gelu_poly_grad(vl, d0); vr = gelu_poly_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
                     l[e] = vl; r[e] = vr;
                 }
                 emit(l, r, Cb, row0);

@@ -14,6 +14,10 @@ from simseg_amd.lib import call, ptr  # noqa: E402
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (100864, 2304, 768)
 kind = sys.argv[4] if len(sys.argv) > 4 else "nt"
 stagger = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+act = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+kw = {}
+if act == 3:
+    kw = dict(act=3, bias=torch.zeros(N, device="cuda"), aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
 call("simseg_debug_gemm_stagger", stagger)
 a = torch.randn(M, K, device="cuda").bfloat16()
 b = (torch.randn(K, N, device="cuda") if kind == "nn" else torch.randn(N, K, device="cuda")).bfloat16()
@@ -21,9 +25,9 @@ tiles = ((M + 255) // 256) * ((N + 255) // 256)
 buf = torch.zeros(tiles * 9, device="cuda", dtype=torch.int64)
 ops.set_gemm_variant(3)
 for _ in range(3):
-    ops.gemm(a, b, trans_b=(kind == "nn"))
+    ops.gemm(a, b, trans_b=(kind == "nn"), **kw)
 call("simseg_debug_gemm_trace", ptr(buf))
-ops.gemm(a, b, trans_b=(kind == "nn"))
+ops.gemm(a, b, trans_b=(kind == "nn"), **kw)
 call("simseg_debug_gemm_trace", None)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy()
@@ -39,7 +43,7 @@ print(f"epilogue split (wave 0): until its last store is issued {(issued - us[:,
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    ops.gemm(a, b, trans_b=(kind == "nn"))
+    ops.gemm(a, b, trans_b=(kind == "nn"), **kw)
 e1.record()
 torch.cuda.synchronize()
 print(f"stagger {stagger} ticks: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per launch (untraced)")
