@@ -1077,6 +1077,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                     for (int e = 0; e < 16; ++e) { l[e] = acc[i][0][e] * p.alpha + bL; r[e] = acc[i][1][e] * p.alpha + bR; }
                     emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
                 }
+            } else if (p.act == 3 && Xb) {     // the training forward of fc1: GELU stored, GELU' saved - unrolled (static accumulator indices)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x16 l, r, dl, dr;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float d0, d1;
+                        l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
+                        r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
+                        dl[e] = d0; dr[e] = d1;
+                    }
+                    const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+                    emit(l, r, Cb, row0);
+                    emit(dl, dr, Xb, row0);
+                }
             } else
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
