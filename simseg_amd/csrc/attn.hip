@@ -1455,7 +1455,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
             qr[kk] = uq.hh; gr[kk] = ug.hh;
         }
         const float lse = qvalid ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;
-        const float del = qvalid ? p.delta[((long)b * p.H + h) * T + q] : 0.f;
+        // delta = rowsum(dO o O) of this lane's query, from the dO slices it already holds (this kernel runs FIRST and leaves delta for
+        // the dK / dV kernel: no separate pass over O and dO)
+        float del = 0.f;
+        if (qvalid) {
+            const bf16_t* obase = static_cast<const bf16_t*>(p.out) + (long)b * T * OS + h * 64 + (long)q * OS;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 o8 = ld_bf16x8(obase + (2 * kk + h2) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) del += (float)o8[e] * (float)gr[kk][e];
+            }
+        }
+        del += __shfl_xor(del, 32, 64);
+        if (qvalid && h2 == 0) const_cast<float*>(p.delta)[((long)b * p.H + h) * T + q] = del;
         if (!landed) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1545,8 +1558,8 @@ int launch_bwd_res(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const dim3 grid((unsigned)(p.B * p.H)), block((q32 < 4 ? q32 : 4) * 64);
-    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<DROP>, grid, block, smem, stream, p);
-    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DROP>, grid, block, smem, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DROP>, grid, block, smem, stream, p);       // dQ; computes and writes delta
+    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<DROP>, grid, block, smem, stream, p);      // dK, dV (reads delta)
     return 0;
 }
 
@@ -1659,12 +1672,14 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
         return 0;
     }
     const long groups = B * T * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
-                       (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
-    if (T <= RES_MAXT && g_attn_variant != 1) {
+    const bool resident = T <= RES_MAXT && g_attn_variant != 1;
+    if (!resident)       // (the resident dQ kernel forms delta itself)
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
+                           (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
+    if (resident) {
         if (int rc = p.drop_thresh ? launch_bwd_res<true>(p, s) : launch_bwd_res<false>(p, s)) return rc;
     } else if (p.drop_thresh) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
