@@ -561,7 +561,9 @@ def main():
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
                        "gradient_sync": ("none" if world == 1 else (f"simseg_amd.parallel.GradSync ({dp})" if sync is not None else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
-                       "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)"},
+                       "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",
+                       "captions": "ragged, lengths U{8..L}" + ("; the padded token rows of the text tower are not computed (same loss and "
+                                   "gradients as computing them: SIMSEG_AMD_PACKED_TEXT=0)" if os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0" else "; padded token rows computed")},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,

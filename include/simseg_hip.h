@@ -168,6 +168,9 @@ int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32
 
 int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);
+/* dst[i,:] = src[idx[i],:] (idx[i] < 0: a zero row); rows of row_bytes (a multiple of 16) bytes, any dtype.  Drops / restores the padded
+ * token rows of ragged caption batches around the text tower's GEMMs (HF BertModel computes them: huggingface_builder.py:16-17). */
+int simseg_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t row_bytes, void* stream);
 /* g[i] = keep(seed, i) ? g[i] / (1-p) : 0 -- regenerates the forward dropout mask of simseg_gemm for the backward. */
 int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream);
 

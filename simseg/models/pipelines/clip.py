@@ -15,7 +15,7 @@ from simseg.models.pipelines.builder import PIPELINE
 from simseg.utils import ENV
 from simseg_amd.heads import prefetch_gather
 from simseg_amd.nn import compute_dtype
-from simseg_amd.towers import ProjectPoolFn
+from simseg_amd.towers import ProjectPoolFn, packed_text
 
 from ..components import AvgPooling, ComplexProjection, L2norm, SimpleProjection, TopKPooling
 from ..components.pooling import clip_k_to_shortest
@@ -113,7 +113,7 @@ class CLIPModel(nn.Module):
             # (which tower is enqueued first makes no measurable difference: 126.2 vs 126.4 ms/step)
             img = self.forward_image_project(self.forward_image_feature(image))
             self._prefetch(img, embeddings)          # the image embeddings travel while the text tower is still computing
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), packed_text():
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
                 self._prefetch(txt, embeddings)
             main.wait_stream(side)
@@ -128,7 +128,8 @@ class CLIPModel(nn.Module):
         else:
             img = self.forward_image_project(self.forward_image_feature(image))
             self._prefetch(img, embeddings)
-            txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
+            with packed_text():      # only the masked pooling reads the text tower's output here: padded token rows are not computed
+                txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
         if embeddings == "all":
             return [img, txt]
         return self.forward_loss(img, txt, ignore_mask=None)

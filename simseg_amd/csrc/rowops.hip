@@ -776,6 +776,34 @@ extern "C" int simseg_transpose_f32(const float* in, float* out, int64_t R, int6
     return 0;
 }
 
+// Row gather: dst[i,:] = src[idx[i],:] for i < n (idx < 0: a zero row).  Rows are `chunks` 16-byte pieces wide; dtype-agnostic.
+// The text tower uses it to drop the padded token rows of a ragged caption batch before its GEMMs / LayerNorms and to put rows back
+// (idx = inverse map, -1 at padded positions -> zeros) around the attention kernels, which keep the dense [B, L] layout.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, const int* __restrict__ idx, u32x4* __restrict__ dst,
+                                                          long n, int chunks) {
+    const long total = n * chunks;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / chunks;
+        const int c = (int)(t - i * chunks);
+        const int r = idx[i];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r >= 0) v = src[(long)r * chunks + c];
+        dst[t] = v;
+    }
+}
+
+extern "C" int simseg_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t row_bytes, void* stream) {
+    SS_CHECK(src && idx && dst, "gather_rows: null pointer");
+    SS_CHECK(row_bytes > 0 && row_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+             "gather_rows: rows must be multiples of 16 bytes and 16-byte aligned");
+    if (n <= 0) return 0;
+    const long total = n * (row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)grid_for(total, 256, 16384)), dim3(256), 0, STREAM, (const u32x4*)src, idx, (u32x4*)dst,
+                       (long)n, (int)(row_bytes / 16));
+    SS_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+
 extern "C" int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream) {
     SS_CHECK(g, "dropout_apply: null pointer");
     SS_CHECK(p >= 0.f && p < 1.f, "dropout_apply: p out of range");

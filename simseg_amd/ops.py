@@ -240,6 +240,18 @@ def transpose_f32(x2d):
     return out
 
 
+def gather_rows(src2d, idx, out=None):
+    """out[i] = src2d[idx[i]] (zero row where idx[i] < 0).  idx int32 on the device."""
+    require_gpu(src2d, idx)
+    if idx.dtype != torch.int32:
+        raise TypeError("gather_rows: idx must be int32")
+    n, w = idx.numel(), src2d.shape[-1]
+    if out is None:
+        out = torch.empty(n, w, device=src2d.device, dtype=src2d.dtype)
+    call("simseg_gather_rows", ptr(_c(src2d)), ptr(_c(idx)), ptr(_c(out)), n, w * src2d.element_size(), stream())
+    return out
+
+
 def dropout_apply_(g, seed, p):
     call("simseg_dropout_apply", ptr(_c(g)), dt(g), g.numel(), int(seed), float(p), stream())
     return g

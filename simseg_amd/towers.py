@@ -375,12 +375,42 @@ class BertEmbedFn(Function):
         return None, None, dword, dpos, dtyp, dg, db, None, None
 
 
+class RowMapFn(Function):
+    """y[i] = x[fwd_map[i]] (a zero row where the map is -1); the backward is the same gather with the inverse map.  With
+    fwd_map = the flat positions of the real tokens it PACKS a ragged caption batch [B*L, D] -> [Nv, D]; with the inverse map (-1 at
+    padded positions) it puts the rows back."""
+
+    @staticmethod
+    def forward(ctx, x2d, fwd_map, bwd_map):
+        ctx.save_for_backward(bwd_map)
+        return ops.gather_rows(x2d.contiguous(), fwd_map)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (bwd_map,) = ctx.saved_tensors
+        return ops.gather_rows(dy.contiguous(), bwd_map), None, None
+
+
+def ragged_maps(mask):
+    """(idx [Nv] flat positions of the real tokens, inv [B*L] packed row of every position or -1), both int32, for a [B, L] 0/1 mask."""
+    flat = mask.reshape(-1) != 0
+    idx = flat.nonzero().flatten().to(torch.int32)
+    inv = torch.full((flat.numel(),), -1, device=mask.device, dtype=torch.int32)
+    inv[idx.long()] = torch.arange(idx.numel(), device=mask.device, dtype=torch.int32)
+    return idx, inv
+
+
 class BertLayerFn(Function):
     """HF BertLayer (post-LN, eps 1e-12): a = LN(x + drop(dense(attn(x)))); y = LN(a + drop(dense(gelu(dense(a)))))."""
 
     @staticmethod
-    def forward(ctx, x, mask, heads, adt, drop_p, seed, qw, qb, kw, kb, vw, vb, ow, ob, law, lab, iw, ib, o2w, o2b, low, lob):
-        B, L, D = x.shape
+    def forward(ctx, x, mask, heads, adt, drop_p, seed, qw, qb, kw, kb, vw, vb, ow, ob, law, lab, iw, ib, o2w, o2b, low, lob, idx=None, inv=None):
+        # idx / inv given: x is [Nv, D], the real tokens of the ragged batch only (padded rows dropped).  Every GEMM, LayerNorm and
+        # dropout then runs on Nv rows; only the attention kernels see the dense [B, L] layout (rows put back with zeros at the padded
+        # positions: masked keys, and queries whose outputs are never read).
+        packed = idx is not None
+        B, L = mask.shape
+        D = x.shape[-1]
         x = x.contiguous()
         save = any(ctx.needs_input_grad)
         xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
@@ -390,24 +420,30 @@ class BertLayerFn(Function):
             bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
         ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
         qkv = ops.gemm(xa, wqkv, bias=bqkv)
+        if packed:
+            qkv = ops.gather_rows(qkv, inv)                          # [B*L, 3D], zero rows at the padded positions
         att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p)
+        attd = att
+        if packed:
+            att = ops.gather_rows(att.view(-1, D), idx)              # [Nv, D]
         s1 = ops.gemm(att.view(-1, D), ow_, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
         aa = a32 if adt == F32 else a16
-        pre = torch.empty(B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
+        pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
         act = ops.gemm(aa, iw_, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, _, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, save_stats=save)
-        ctx.adt, ctx.heads, ctx.dims, ctx.drop = adt, heads, (B, L, D), (drop_p, seed)
+        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed = adt, heads, (B, L, D), (drop_p, seed), packed
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
-                                  law.detach(), low.detach())
-        return y.view(B, L, D)
+                                  law.detach(), low.detach(), attd if packed else None, idx, inv)
+        return y if packed else y.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
-        (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low) = ctx.saved_tensors
+        (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low, attd, idx, inv) = ctx.saved_tensors
         B, L, D = ctx.dims
+        packed = ctx.packed
         adt = ctx.adt
         p, seed = ctx.drop
         need = ctx.needs_input_grad
@@ -427,15 +463,41 @@ class BertLayerFn(Function):
                              drop=(p, seed + 1))
         datt = _dgrad(d1, ow_)
         dow = _wgrad(d1, att.view(-1, D), dow_z) if need[12] else None
-        dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), att, datt.view(B, L, D), lse, ctx.heads, mask, scale=64 ** -0.5,
-                                 drop_seed=seed, drop_p=p).view(-1, 3 * D)
+        if packed:
+            datt = ops.gather_rows(datt, inv)                        # back to [B*L, D] (zero rows at the padded positions)
+        dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
+                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p).view(-1, 3 * D)
+        if packed:
+            dqkv = ops.gather_rows(dqkv, idx)                        # [Nv, 3D]
         dx = _dgrad(dqkv, wqkv, residual=ds1_32, out_dtype=F32)
         dwqkv = _wgrad(dqkv, xa, dwqkv_z) if (need[6] or need[8] or need[10]) else None
         dbqkv = _bgrad(dqkv, dbqkv_z) if (need[7] or need[9] or need[11]) else None
         dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]
         dbs = [dbqkv[i * D:(i + 1) * D] if dbqkv is not None else None for i in range(3)]
-        return (dx.view(B, L, D), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dow, dob, dlaw, dlab,
-                diw, dib, do2w, do2b, dlow, dlob)
+        return (dx if packed else dx.view(B, L, D), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dow, dob,
+                dlaw, dlab, diw, dib, do2w, do2b, dlow, dlob, None, None)
+
+
+# Ragged caption batches.  HF's BertModel computes every padded token (huggingface_builder.py:16-17); nothing downstream of the CLIP
+# pipeline reads those rows (the key-padding mask hides them from the real tokens, the masked top-1 pooling of forward_text_project
+# drops them, their gradients are exactly zero).  Inside `packed_text()` - which CLIPModel.forward enters around its text branch - the
+# tower therefore runs its GEMMs, LayerNorms and dropout on the real tokens only and returns zeros at the padded positions; loss,
+# accuracies and every parameter gradient are those of the dense computation.  The plain `forward_text_feature` API stays dense, so its
+# [B, L, 768] output equals the reference's at every position.  SIMSEG_AMD_PACKED_TEXT=0 switches the packing off.
+import contextlib
+import os
+
+_PACK_TEXT = [False]
+
+
+@contextlib.contextmanager
+def packed_text():
+    prev = _PACK_TEXT[0]
+    _PACK_TEXT[0] = os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0"
+    try:
+        yield
+    finally:
+        _PACK_TEXT[0] = prev
 
 
 def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
@@ -448,13 +510,24 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     mask = attention_mask.contiguous().long()
     x = BertEmbedFn.apply(input_ids, mask, e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
                           e.LayerNorm.weight, e.LayerNorm.bias, p_h, seed)
+    B, L, D = x.shape
+    idx = inv = None
+    if _PACK_TEXT[0] and x.is_cuda:
+        idx, inv = ragged_maps(mask)
+        if idx.numel() == B * L or idx.numel() == 0:
+            idx = inv = None                                        # nothing to drop
+        else:
+            x = RowMapFn.apply(x.view(-1, D), idx, inv)             # [Nv, D]
     for i, lyr in enumerate(m.encoder.layer):
         a, s = lyr.attention, lyr.attention.self
         x = BertLayerFn.apply(x, mask, m.num_heads, adt, p_h, seed + 16 * (i + 1),
                               s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
                               a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
                               lyr.intermediate.dense.weight, lyr.intermediate.dense.bias,
-                              lyr.output.dense.weight, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias)
+                              lyr.output.dense.weight, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias,
+                              idx, inv)
+    if idx is not None:
+        x = RowMapFn.apply(x, inv, idx).view(B, L, D)               # zeros at the padded positions
     return x
 
 

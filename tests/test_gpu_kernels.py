@@ -213,6 +213,18 @@ def test_gemm_pingpong_accumulator_layout_epilogues(ops, tb, M, N, K):
     assert float(((d3.abs() < 1e-6) != (d1.abs() < 1e-6)).float().mean()) < 1e-3          # the same dropout mask
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_rows(ops, dtype):
+    """Row gather with -1 -> zero row (packing / unpacking the real tokens of a ragged caption batch)."""
+    src = _rand(1000, 768, seed=1, dtype=dtype)
+    idx = torch.randint(-1, 1000, (2500,), generator=torch.Generator().manual_seed(2)).to(torch.int32).cuda()
+    out = ops.gather_rows(src, idx)
+    want = torch.where((idx >= 0)[:, None], src[idx.clamp(min=0).long()], torch.zeros((), device="cuda", dtype=dtype))
+    assert torch.equal(out, want)
+    with pytest.raises(TypeError):
+        ops.gather_rows(src, idx.long())
+
+
 def test_gemm_bf16_splitk_and_dgelu(ops):
     K, M, N = 5000, 256, 384          # wgrad shape: contraction over rows
     dy, x = _rand(K, M, seed=1, dtype=torch.bfloat16), _rand(K, N, seed=2, dtype=torch.bfloat16)

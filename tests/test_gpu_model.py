@@ -261,6 +261,48 @@ def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monke
     assert worst < 1e-4
 
 
+def test_packed_text_tower_equals_dense(golden, monkeypatch):
+    """Ragged captions: inside CLIPModel.forward the text tower drops the padded token rows (GEMMs / LayerNorms on the real tokens only,
+    the attention kernels on the dense layout with zero rows put back).  Loss, accuracies and every parameter gradient equal those of the
+    dense computation (SIMSEG_AMD_PACKED_TEXT=0), in exact fp32 to rounding; the plain forward_text_feature API stays dense."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    from simseg_amd import towers
+    g = golden("clip_train_ws1")
+    batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    assert 0 < int(batch["attention_mask"].sum()) < batch["attention_mask"].numel()          # the fixture batch is ragged
+    res = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("SIMSEG_AMD_PACKED_TEXT", packed)
+        m = _build(golden)
+        m.eval()
+        calls = []
+        orig = towers.ragged_maps
+        monkeypatch.setattr(towers, "ragged_maps", lambda mask: (calls.append(1), orig(mask))[1])
+        loss_dict, a1, a2 = m(batch)
+        loss_dict["nce_loss"].backward()
+        monkeypatch.setattr(towers, "ragged_maps", orig)
+        assert len(calls) == (1 if packed == "1" else 0)                                       # the packed path is the one that ran
+        res[packed] = (loss_dict["nce_loss"].item(), a1.item(), a2.item(), {n: p.grad.clone() for n, p in m.named_parameters()})
+        with torch.no_grad():
+            feat = m.forward_text_feature(batch["input_ids"], batch["attention_mask"])
+        assert _maxerr(feat, tt(g["r0.txt_feat"])) < 1e-3 if "r0.txt_feat" in g.files else True
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-6)
+    assert res["1"][1:3] == res["0"][1:3]
+    for n, gd in res["0"][3].items():
+        err = float((res["1"][3][n] - gd).abs().max() / (gd.abs().max() + 1e-30))
+        if "key.bias" in n:
+            continue
+        assert err < 1e-4, (n, err)
+    # dropout active (train mode, bf16): runs, finite
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    monkeypatch.setenv("SIMSEG_AMD_PACKED_TEXT", "1")
+    m = _build(golden)
+    m.train()
+    loss = m(batch)[0]["nce_loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_full_size_vs_oracle(monkeypatch):
     """ViT-S @224 + BERT-base on config-1-shaped input (4 images, 20 prompts): kernels vs the CPU oracle."""
     monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
