@@ -1387,7 +1387,9 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         if (v == 6) v = 0;
         if (v == 7) v = 1;
     }
-    if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 256) ? 3 : 1;
+    // (measured, tools/gemm_mid_bench.py: the ping-pong kernel is ahead of the 128x128 one from ~96 of its tiles on - e.g. the packed text
+    //  tower's ~22 k x 768 problems, 255 tiles: 34 vs 52 us at K = 768, 98 vs 151 us at K = 3072)
+    if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 96) ? 3 : 1;
     // one round of 128x128 tiles (more than the small-problem kernel takes, at most a block per CU): the ring variant's three slabs in
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

@@ -391,13 +391,19 @@ class RowMapFn(Function):
         return ops.gather_rows(dy.contiguous(), bwd_map), None, None
 
 
-def ragged_maps(mask):
-    """(idx [Nv] flat positions of the real tokens, inv [B*L] packed row of every position or -1), both int32, for a [B, L] 0/1 mask."""
+def ragged_maps(mask, multiple=256):
+    """(idx [Np] flat positions of the real tokens, inv [B*L] packed row of every position or -1, number of real tokens), maps int32, for
+    a [B, L] 0/1 mask.  idx is padded with -1 (zero rows, which receive zero gradients and are never put back) to a multiple of the GEMM
+    tile height: every row tile is a full tile (fast epilogues) and the weight-gradient contraction length stays a multiple of 64."""
     flat = mask.reshape(-1) != 0
     idx = flat.nonzero().flatten().to(torch.int32)
+    nv = idx.numel()
     inv = torch.full((flat.numel(),), -1, device=mask.device, dtype=torch.int32)
-    inv[idx.long()] = torch.arange(idx.numel(), device=mask.device, dtype=torch.int32)
-    return idx, inv
+    inv[idx.long()] = torch.arange(nv, device=mask.device, dtype=torch.int32)
+    pad = (-nv) % multiple
+    if pad and nv + pad < flat.numel():
+        idx = torch.cat([idx, torch.full((pad,), -1, device=mask.device, dtype=torch.int32)])
+    return idx, inv, nv
 
 
 class BertLayerFn(Function):
@@ -513,8 +519,8 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     B, L, D = x.shape
     idx = inv = None
     if _PACK_TEXT[0] and x.is_cuda:
-        idx, inv = ragged_maps(mask)
-        if idx.numel() == B * L or idx.numel() == 0:
+        idx, inv, nv = ragged_maps(mask)
+        if nv == 0 or idx.numel() >= B * L:
             idx = inv = None                                        # nothing to drop
         else:
             x = RowMapFn.apply(x.view(-1, D), idx, inv)             # [Nv, D]
