@@ -179,8 +179,10 @@ def class_text_embeddings(model, input_ids, attention_mask, chunk=2048):
     C, Pn, L = input_ids.shape
     ids, mask = input_ids.reshape(C * Pn, L), attention_mask.reshape(C * Pn, L)
     embs = []
+    from .towers import packed_text
     for s in range(0, C * Pn, chunk):
-        feats = model.forward_text_feature(ids[s:s + chunk], mask[s:s + chunk])
-        embs.append(model.forward_text_project(feats, mask[s:s + chunk]))
+        with packed_text():          # only the masked pooling reads the tower's output: the prompts' padded token rows are not computed
+            feats = model.forward_text_feature(ids[s:s + chunk], mask[s:s + chunk])
+            embs.append(model.forward_text_project(feats, mask[s:s + chunk]))
     emb = torch.cat(embs).float().view(C, Pn, -1)
     return ops.segment_mean_l2norm(emb.contiguous())
