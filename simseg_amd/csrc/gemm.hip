@@ -1379,8 +1379,9 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         // kernel; for the 256x256 kernel pick the largest count that still fits ONE round of 256 blocks (a 288-block launch
         // runs two rounds, the second 12 % full)
         if ((v == 0 || v == 6 || v == 3) && v != 7 && big_ok && p.accumulate && splitk > 1 && p.M % 256 == 0 && p.N % 256 == 0 && tiles256 <= 128) {
-            const int sk = 256 / tiles256;
-            if (nk64 / sk >= 16 && (v == 3 || v == 0)) { g_gemm_last_variant = 3; return launch_pp<TO, TA, TB>(p, sk, s); }
+            int sk = 256 / tiles256;
+            if (nk64 / sk < 16 && nk64 >= 64) sk = nk64 / 16;        // short contraction (packed text rows): fewer, 16-deep slices
+            if (nk64 / sk >= 16 && tiles256 * sk >= 96 && (v == 3 || v == 0)) { g_gemm_last_variant = 3; return launch_pp<TO, TA, TB>(p, sk, s); }
             if (nk64 / sk >= 16 && v == 6) { g_gemm_last_variant = 2; return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, sk, s); }
         }
         if (v == 3) v = 0;
