@@ -113,13 +113,16 @@ int simseg_debug_gemm_stagger(int ticks);
  * (log2 domain, optional) is saved for the backward.  dtype 0 = exact fp32 MFMA, 1 = bf16 MFMA.  drop_p > 0 applies
  * HF attention_probs dropout.  Replaces timm Attention.forward (q@k^T*scale, softmax, @v) and HF
  * BertSelfAttention.forward as reached through vit_builder.py:18 / huggingface_builder.py:16-17. */
+/* skip_padded_rows (bf16, T <= 256, with a key mask): the caller neither reads the outputs nor uses the gradients of the rows past a
+ * sequence's last unmasked key (the packed text tower): the kernels then work on 1 + that key's index rows of each sequence only and
+ * leave the other rows of out / lse / dqkv untouched. */
 int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B, int64_t T,
-                         int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream);
+                         int64_t H, float scale, uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
 /* Backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse, all in `dtype` (0 = fp32: the exact mode of a non-AMP run,
  * simseg/core/hooks/optimizer.py:76-77; 1 = bf16); delta[B,H,T] is caller-provided fp32 scratch. */
 int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
                          float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
-                         uint64_t drop_seed, float drop_p, void* stream);
+                         uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
 
 /* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).
  * tools/seg_evaluation.py:71-73 (class_embeddings.mean(dim=0); /= norm()). */

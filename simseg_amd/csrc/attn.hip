@@ -27,6 +27,7 @@ struct AttnParams {
     // backward
     const void* dout; const float* delta; void* dqkv;
     int dbg;            // resident kernels, benchmarking only: 2 = skip the K/V copy, 3 = skip the tile loop
+    int pack;           // resident kernels: rows past the last unmasked key of a sequence are neither read nor written (see attn_teff)
 };
 
 // online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
@@ -720,15 +721,34 @@ constexpr int RES_AUTO_T = 256;          // measured (tools/dbg_attn_res.py): re
 // allocation granule (a 3 KiB guard behind V cost the third block: 202 -> 225 us).
 __device__ __forceinline__ int res_rows8(int T) { return (T + 7) & ~7; }
 
+// Effective length of sequence b for the resident kernels when the caller has dropped the padded rows from everything around the
+// attention (towers.packed_text): 1 + the last unmasked key.  Keys past it are masked (their probabilities are exactly 0), and the
+// caller neither reads the outputs nor uses the gradients of the query rows past it, so the kernels treat the sequence as T_eff long:
+// fewer rows copied, fewer tiles.  Block-uniform; p.T when the flag is off, there is no mask, or every key is masked.
+__device__ __forceinline__ int attn_teff(const AttnParams& p, int b) {
+    if (!p.pack || !p.mask) return p.T;
+    __shared__ int sh_last[4];
+    int last = -1;
+    for (int j = threadIdx.x; j < p.T; j += blockDim.x)
+        if (p.mask[(long)b * p.T + j] != 0) last = j;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_last[threadIdx.x >> 6] = last;
+    __syncthreads();
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) last = max(last, sh_last[w]);
+    __syncthreads();
+    return last < 0 ? p.T : last + 1;
+}
+
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_bf16_res_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
-    const int T = p.T;
+    const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
     const long RS = 3L * p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int HD = p.H * 64;
     const int nt = (T + KT - 1) / KT, q32 = (T + 31) / 32;
@@ -750,7 +770,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     if (MASK) {
         for (int key = tid; key < nt * KT; key += nthr)
-            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * Tf + key] != 0)) ? 0.f : NEG;
     }
     // this wave's query tiles: wave, wave + nw (T <= 256 and nw = min(4, q32): at most two).  The first tile's Q rows are fetched
     // with the K / V copies; the second tile's replace them as soon as the first pass has formed its last scores.
@@ -843,7 +863,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                        const unsigned idx = ((unsigned)bh_ * T + q) * T + key;                 // < 2^32: checked by the host
+                        const unsigned idx = ((unsigned)bh_ * Tf + q) * Tf + key;                 // < 2^32: checked by the host
                         s[kb][r] = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? s[kb][r] * p.drop_scale : 0.f;
                     }
             }
@@ -868,7 +888,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float ltot = lsum + __shfl_xor(lsum, 32, 64);
         const float inv = 1.0f / ltot;
         if (q < T) {
-            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * T + q) * p.H * 64 + h * 64;
+            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * Tf + q) * p.H * 64 + h * 64;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -877,7 +897,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     bf16x4 v = {(bf16_t)(o[db][4 * r4] * inv), (bf16_t)(o[db][4 * r4 + 1] * inv), (bf16_t)(o[db][4 * r4 + 2] * inv), (bf16_t)(o[db][4 * r4 + 3] * inv)};
                     *reinterpret_cast<bf16x4*>(orow + d) = v;
                 }
-            if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+            if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * Tf + q] = m + log2f(ltot);
         }
     }
 }
@@ -1283,10 +1303,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, kl = lane & 31;
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
-    const int T = p.T;
+    const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
-    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int q32 = (T + 31) / 32, rows32 = q32 * 32;
     char* ldsQ = lds;
@@ -1296,8 +1316,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
     res_copy_rows(base, RS, T, rows32, ldsQ, wave, nw, lane);
     res_copy_rows(gbase, OS, T, rows32, ldsG, wave, nw, lane);
     for (int q = tid; q < rows32; q += nthr) {
-        lse_l[q] = q < T ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;            // -> P = 0 for padded queries
-        del_l[q] = q < T ? p.delta[((long)b * p.H + h) * T + q] : 0.f;
+        lse_l[q] = q < T ? p.lse[((long)b * p.H + h) * Tf + q] : 1e30f;            // -> P = 0 for padded queries
+        del_l[q] = q < T ? p.delta[((long)b * p.H + h) * Tf + q] : 0.f;
     }
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const float scale = p.scale_log2e * 0.6931471805599453f;
@@ -1311,7 +1331,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
     for (int kt = wave; kt < q32; kt += nw) {
         const int key = kt * 32 + kl;
         const bool kvalid = key < T;
-        const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        const float kb_ = (kvalid && (!p.mask || p.mask[(long)b * Tf + key] != 0)) ? 0.f : NEG;
         bf16x8 kr[4], vr[4];     // this lane's K and V row chunks: B operands of S = Q.K^T and dP = dO.V^T
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -1379,7 +1399,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
                 float keep = 1.f;
                 if (DROP) {
                     const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned idx = ((unsigned)bh_ * T + (q0 + qq)) * T + key;
+                    const unsigned idx = ((unsigned)bh_ * Tf + (q0 + qq)) * Tf + key;
                     keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
                 }
                 pd[r] = pr * keep;                                   // dropped probabilities feed dV
@@ -1400,7 +1420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
         }
         // dk/dv accumulators (transposed): column = this lane's key, rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
         if (kvalid) {
-            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)key * RS;
+            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)key * RS;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1411,6 +1431,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
                 }
         }
     }
+    if (!landed) {       // a wave without a tile (short effective length): its share of the copies still has to land before the others read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 }
 
 template <bool DROP>
@@ -1419,10 +1443,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
-    const int T = p.T;
+    const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
-    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * T * OS + h * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int q32 = (T + 31) / 32, rows32 = q32 * 32;
     char* ldsK = lds;
@@ -1431,7 +1455,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
     res_copy_rows(base + p.H * 64, RS, T, rows32, ldsK, wave, nw, lane);
     res_copy_rows(base + 2 * p.H * 64, RS, T, rows32, ldsV, wave, nw, lane);
     for (int key = tid; key < rows32; key += nthr)
-        kbias[key] = (key < T && (!p.mask || p.mask[(long)b * T + key] != 0)) ? 0.f : NEG;
+        kbias[key] = (key < T && (!p.mask || p.mask[(long)b * Tf + key] != 0)) ? 0.f : NEG;
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const float scale = p.scale_log2e * 0.6931471805599453f;
     const int arow = ql * 128, asw = qd_swz(ql);
@@ -1454,12 +1478,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
             }
             qr[kk] = uq.hh; gr[kk] = ug.hh;
         }
-        const float lse = qvalid ? p.lse[((long)b * p.H + h) * T + q] : 1e30f;
+        const float lse = qvalid ? p.lse[((long)b * p.H + h) * Tf + q] : 1e30f;
         // delta = rowsum(dO o O) of this lane's query, from the dO slices it already holds (this kernel runs FIRST and leaves delta for
         // the dK / dV kernel: no separate pass over O and dO)
         float del = 0.f;
         if (qvalid) {
-            const bf16_t* obase = static_cast<const bf16_t*>(p.out) + (long)b * T * OS + h * 64 + (long)q * OS;
+            const bf16_t* obase = static_cast<const bf16_t*>(p.out) + (long)b * Tf * OS + h * 64 + (long)q * OS;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 o8 = ld_bf16x8(obase + (2 * kk + h2) * 8);
@@ -1468,7 +1492,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
             }
         }
         del += __shfl_xor(del, 32, 64);
-        if (qvalid && h2 == 0) const_cast<float*>(p.delta)[((long)b * p.H + h) * T + q] = del;
+        if (qvalid && h2 == 0) const_cast<float*>(p.delta)[((long)b * p.H + h) * Tf + q] = del;
         if (!landed) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1519,7 +1543,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
                 float keep = 1.f;
                 if (DROP) {
                     const int kk_ = k0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    const unsigned idx = ((unsigned)bh_ * T + q) * T + kk_;
+                    const unsigned idx = ((unsigned)bh_ * Tf + q) * Tf + kk_;
                     keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
                 }
                 ds[r] = pr * (dp[r] * keep - del) * scale;
@@ -1535,13 +1559,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
             }
         }
         if (qvalid) {
-            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * T * RS + h * 64 + (long)q * RS;
+            bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)q * RS;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
                     store_bf16x4(drow + db * 32 + 8 * r4 + 4 * h2, dq[db][4 * r4], dq[db][4 * r4 + 1], dq[db][4 * r4 + 2], dq[db][4 * r4 + 3]);
         }
+    }
+    if (!landed) {       // a wave without a tile (short effective length): its share of the copies still has to land before the others read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 
@@ -1605,9 +1633,11 @@ extern "C" int simseg_set_attention_variant(int v) {
 
 // ctx[B,T,H*64] = softmax(q k^T * scale + keymask) v  from packed qkv[B,T,3,H,64]; lse[B,H,T] (log2 domain) optional.
 extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B,
-                                    int64_t T, int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream) {
+                                    int64_t T, int64_t H, float scale, uint64_t drop_seed, float drop_p, int skip_padded_rows,
+                                    void* stream) {
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
+    p.pack = skip_padded_rows && key_mask && dtype == 1 && T <= RES_MAXT;
     SS_CHECK(out, "attention_fwd: null out");
     SS_CHECK(dtype == 0 || !(key_mask || drop_p > 0.f) || T <= MAXT_BIAS, "attention_fwd: masked bf16 sequences are limited to %d keys", MAXT_BIAS);
     p.out = out; p.lse = lse;
@@ -1649,9 +1679,10 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
 // `dtype` (0 = fp32 exact mode, 1 = bf16).
 extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
                                     float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
-                                    uint64_t drop_seed, float drop_p, void* stream) {
+                                    uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream) {
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
+    p.pack = skip_padded_rows && key_mask && dtype == 1 && T <= RES_MAXT;
     SS_CHECK(out && dout && lse && delta && dqkv, "attention_bwd: null pointer");
     SS_CHECK(dtype == 0 || dtype == 1, "attention_bwd: dtype must be 0 (fp32) or 1 (bf16)");
     p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta; p.dqkv = dqkv;

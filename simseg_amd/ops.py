@@ -172,7 +172,7 @@ def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8, normalize=Tru
     return dtok
 
 
-def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0):
+def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0, skip_padded_rows=False):
     """qkv [B,T,3*H*64] packed (3,H,64) -> ctx [B,T,H*64]."""
     require_gpu(qkv)
     B, T, W = qkv.shape
@@ -182,17 +182,17 @@ def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
     _push_variant("attention")
     call("simseg_attention_fwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(out), ptr(lse), dt(qkv), B, T, heads, float(scale),
-         int(drop_seed), float(drop_p), stream())
+         int(drop_seed), float(drop_p), int(skip_padded_rows), stream())
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0):
+def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0, skip_padded_rows=False):
     B, T, W = qkv.shape
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
     _push_variant("attention")
     call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(delta), ptr(dqkv),
-         dt(qkv), B, T, heads, float(scale), int(drop_seed), float(drop_p), stream())
+         dt(qkv), B, T, heads, float(scale), int(drop_seed), float(drop_p), int(skip_padded_rows), stream())
     return dqkv
 
 

@@ -428,7 +428,8 @@ class BertLayerFn(Function):
         qkv = ops.gemm(xa, wqkv, bias=bqkv)
         if packed:
             qkv = ops.gather_rows(qkv, inv)                          # [B*L, 3D], zero rows at the padded positions
-        att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p)
+        att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p,
+                                      skip_padded_rows=packed and _SKIP_PAD)
         attd = att
         if packed:
             att = ops.gather_rows(att.view(-1, D), idx)              # [Nv, D]
@@ -472,7 +473,7 @@ class BertLayerFn(Function):
         if packed:
             datt = ops.gather_rows(datt, inv)                        # back to [B*L, D] (zero rows at the padded positions)
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
-                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p).view(-1, 3 * D)
+                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD).view(-1, 3 * D)
         if packed:
             dqkv = ops.gather_rows(dqkv, idx)                        # [Nv, 3D]
         dx = _dgrad(dqkv, wqkv, residual=ds1_32, out_dtype=F32)
@@ -494,6 +495,7 @@ import contextlib
 import os
 
 _PACK_TEXT = [False]
+_SKIP_PAD = os.environ.get("SIMSEG_AMD_SKIP_PAD_ROWS", "1") != "0"      # (A/B switch: attention kernels on the effective lengths)
 
 
 @contextlib.contextmanager

@@ -524,6 +524,35 @@ def test_attention_bwd_fp32_exact(ops, T):
             assert float(dqkv.view(B, T, 3, H, 64)[1, 9:, 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T", [25, 77, 200])
+def test_attention_skip_padded_rows(ops, T):
+    """skip_padded_rows (the packed text tower): the kernels work on the rows up to each sequence's last unmasked key only.  On those
+    rows forward output, log-sum-exp and every gradient equal the dense call's bit for bit (same tiles, same order; with and without
+    dropout); lengths cover one row, tile edges, a hole inside a mask and a fully masked sequence (which falls back to the dense work)."""
+    B, H = 7, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.2, dtype=torch.bfloat16)
+    dout = _rand(B, T, H * 64, seed=T + 1, dtype=torch.bfloat16)
+    lens = [T, 1, min(9, T), min(32, T), min(33, T), T - 1, 0]
+    mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    if T > 20:
+        mask[2, 3] = 0                          # a hole: still masked as a key, still computed as a query
+    for b, n in enumerate(lens):
+        if n > 0:
+            dout[b, n:] = 0                     # the caller's contract: rows past the last unmasked key carry no gradient
+    mask = mask.cuda()
+    for p, seed in ((0.0, 0), (0.1, 99)):
+        out_d, lse_d = ops.attention_fwd(qkv, H, mask, save_lse=True, drop_seed=seed, drop_p=p)
+        out_s, lse_s = ops.attention_fwd(qkv, H, mask, save_lse=True, drop_seed=seed, drop_p=p, skip_padded_rows=True)
+        g_d = ops.attention_bwd(qkv, out_d, dout, lse_d, H, mask, drop_seed=seed, drop_p=p)
+        g_s = ops.attention_bwd(qkv, out_s, dout, lse_s, H, mask, drop_seed=seed, drop_p=p, skip_padded_rows=True)
+        for b, n in enumerate(lens):
+            n = n if n > 0 else T                # nothing unmasked: dense
+            assert torch.equal(out_s[b, :n], out_d[b, :n]) and torch.equal(lse_s[b, :, :n], lse_d[b, :, :n]), (T, b, p)
+            assert torch.equal(g_s[b, :n], g_d[b, :n]), (T, b, p)
+
+
 @pytest.mark.parametrize("T", [77, 197, 600])
 def test_attention_deferred_rescale_branch(ops, T):
     """The online softmax raises its running maximum (and rescales O, l) only when a tile's maximum exceeds it by more than a
