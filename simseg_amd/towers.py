@@ -395,6 +395,9 @@ def ragged_maps(mask, multiple=256):
     """(idx [Np] flat positions of the real tokens, inv [B*L] packed row of every position or -1, number of real tokens), maps int32, for
     a [B, L] 0/1 mask.  idx is padded with -1 (zero rows, which receive zero gradients and are never put back) to a multiple of the GEMM
     tile height: every row tile is a full tile (fast epilogues) and the weight-gradient contraction length stays a multiple of 64."""
+    cached = getattr(mask, "_simseg_ragged", None)      # (the count of real tokens needs a host read: once per mask tensor, not per layer / step)
+    if cached is not None and cached[0] == mask._version and cached[1] == multiple:
+        return cached[2]
     flat = mask.reshape(-1) != 0
     idx = flat.nonzero().flatten().to(torch.int32)
     nv = idx.numel()
@@ -403,6 +406,10 @@ def ragged_maps(mask, multiple=256):
     pad = (-nv) % multiple
     if pad and nv + pad < flat.numel():
         idx = torch.cat([idx, torch.full((pad,), -1, device=mask.device, dtype=torch.int32)])
+    try:
+        mask._simseg_ragged = (mask._version, multiple, (idx, inv, nv))
+    except Exception:       # noqa: BLE001  (a tensor subclass without attribute storage)
+        pass
     return idx, inv, nv
 
 
