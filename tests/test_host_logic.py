@@ -219,3 +219,25 @@ def test_bert_qkv_parameters_are_packed_back_to_back():
     assert w is not None and w.dtype == torch.float64 and torch.equal(w[2 * D:].float(), sd["encoder.layer.1.attention.self.value.weight"])
     s.key.weight.data = s.key.weight.data.clone()                             # someone re-homes a tensor: no longer one block
     assert stacked()[0] is None
+
+
+def test_ragged_maps_for_the_packed_text_tower():
+    """idx lists the real tokens in raster order and is padded with -1 to the GEMM tile height; inv is its inverse (-1 at padded positions);
+    the maps are cached on the mask tensor and recomputed when it is written to."""
+    from simseg_amd.towers import ragged_maps
+    mask = torch.zeros(6, 11, dtype=torch.long)
+    for b, n in enumerate((11, 1, 4, 0, 7, 11)):
+        mask[b, :n] = 1
+    mask[2, 1] = 0                                                  # a hole
+    idx, inv, nv = ragged_maps(mask, multiple=8)
+    real = mask.reshape(-1).nonzero().flatten()
+    assert nv == real.numel() == 32 and idx.dtype == inv.dtype == torch.int32
+    assert idx.numel() % 8 == 0 and torch.equal(idx[:nv].long(), real) and bool((idx[nv:] == -1).all())
+    assert torch.equal(inv[real].long(), torch.arange(nv)) and int((inv == -1).sum()) == mask.numel() - nv
+    assert ragged_maps(mask, multiple=8)[0] is idx                   # cached
+    mask[3, 0] = 1
+    idx2, inv2, nv2 = ragged_maps(mask, multiple=8)
+    assert nv2 == nv + 1 and idx2 is not idx
+    full = torch.ones(2, 5, dtype=torch.long)
+    idx3, _, nv3 = ragged_maps(full, multiple=8)
+    assert nv3 == 10 and idx3.numel() == 10                          # nothing to drop: no padding beyond the dense size
