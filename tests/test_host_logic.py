@@ -231,7 +231,7 @@ def test_ragged_maps_for_the_packed_text_tower():
     mask[2, 1] = 0                                                  # a hole
     idx, inv, nv = ragged_maps(mask, multiple=8)
     real = mask.reshape(-1).nonzero().flatten()
-    assert nv == real.numel() == 32 and idx.dtype == inv.dtype == torch.int32
+    assert nv == real.numel() == 33 and idx.dtype == inv.dtype == torch.int32
     assert idx.numel() % 8 == 0 and torch.equal(idx[:nv].long(), real) and bool((idx[nv:] == -1).all())
     assert torch.equal(inv[real].long(), torch.arange(nv)) and int((inv == -1).sum()) == mask.numel() - nv
     assert ragged_maps(mask, multiple=8)[0] is idx                   # cached
