@@ -482,6 +482,28 @@ def main():
     elapsed = float(elapsed)
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
+    # ---- the same step with the padded caption tokens computed, as HF's BertModel does (secondary figure, same process) ----------
+    dense_text = None
+    if os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0":
+        os.environ["SIMSEG_AMD_PACKED_TEXT"] = "0"
+        try:
+            step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+            dense_text = {"pairs_per_s": round(world * B * args.steps / float(el2), 2), "ms_per_step": round(1e3 * float(el2) / args.steps, 3)}
+        finally:
+            os.environ["SIMSEG_AMD_PACKED_TEXT"] = "1"
+
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
     # The timed steps run the two towers on two HIP streams (their kernels share the GPU, so a per-kernel duration is not
     # that kernel's own speed); the instrumented step runs them on ONE stream so that each launch is timed alone.
@@ -579,7 +601,8 @@ def main():
                            "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
                            "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
-                           "final_loss": round(float(loss.detach()), 4)},
+                           "final_loss": round(float(loss.detach()), 4),
+                           "with_padded_caption_tokens_computed": dense_text},
             "seg_eval": seg,
             "retrieval_eval": retr,
             "cpu_baseline": cpu,
