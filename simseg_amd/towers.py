@@ -8,6 +8,8 @@ that block's backward finishes -- torch DDP's bucketed RCCL all-reduce overlaps 
 
 Reference arithmetic: timm 0.6.13 VisionTransformer as driven by simseg/models/backbones/mml/vit_builder.py:13-21,
 HF BertModel as driven by huggingface_builder.py:16-17 (both third-party; see oracle/simseg_ref.py)."""
+import contextlib
+import os
 import weakref
 
 import torch
@@ -498,9 +500,6 @@ class BertLayerFn(Function):
 # tower therefore runs its GEMMs, LayerNorms and dropout on the real tokens only and returns zeros at the padded positions; loss,
 # accuracies and every parameter gradient are those of the dense computation.  The plain `forward_text_feature` API stays dense, so its
 # [B, L, 768] output equals the reference's at every position.  SIMSEG_AMD_PACKED_TEXT=0 switches the packing off.
-import contextlib
-import os
-
 _PACK_TEXT = [False]
 _SKIP_PAD = os.environ.get("SIMSEG_AMD_SKIP_PAD_ROWS", "1") != "0"      # (A/B switch: attention kernels on the effective lengths)
 
