@@ -103,6 +103,8 @@ int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float
  * whole head's K / V - or Q / dO - in LDS), 1 = always the streaming ring kernels (2 / 3: timing ablations). */
 int simseg_set_attention_variant(int v);
 int simseg_debug_attn_occupancy(int64_t T);
+/* debug (thread-local): the resident dK/dV kernel writes 3 x uint64 per block (start / operands landed / end, 100 MHz wall clock). */
+int simseg_debug_attn_trace(void* buf);
 /* debug (thread-local): the ping-pong GEMM kernel writes 5 x uint64 per block into buf (wall-clock stamps at 100 MHz of block start, K loop
  * start, K loop end, block end; HW_ID) - tools/dbg_gemm_trace.py; NULL switches it off. */
 int simseg_debug_gemm_trace(void* buf);

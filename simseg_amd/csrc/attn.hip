@@ -27,6 +27,7 @@ struct AttnParams {
     // backward
     const void* dout; const float* delta; void* dqkv;
     int dbg;            // resident kernels, benchmarking only: 2 = skip the K/V copy, 3 = skip the tile loop
+    unsigned long long* trace;   // debugging (simseg_debug_attn_trace): per block {start, operands landed, end} wall-clock stamps
     int pack;           // resident kernels: rows past the last unmasked key of a sequence are neither read nor written (see attn_teff)
 };
 
@@ -1304,6 +1305,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
     const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
+    if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 3] = wall_clock64();
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
@@ -1347,6 +1349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             landed = true;
+            if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 3 + 1] = wall_clock64();
         }
         f32x16 dk[2], dv[2];
 #pragma unroll
@@ -1435,6 +1438,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)blockIdx.x * 3 + 2] = wall_clock64(); }
 }
 
 template <bool DROP>
@@ -1597,6 +1601,7 @@ int launch_bwd_res(const AttnParams& p, hipStream_t stream) {
 // for 6-wave blocks) - fewer waves per barrier and per staged K/V tile beat a perfectly filled last block.
 int attn_waves_per_block(int q32) { return q32 <= 4 ? q32 : 4; }
 
+thread_local unsigned long long* g_attn_trace = nullptr;
 thread_local int g_attn_variant = 0;   // tests / benchmarks (thread-local selector): 1 = always the streaming (ring) kernels
 
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
@@ -1610,6 +1615,7 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
     p.qkv = qkv; p.mask = (const long*)mask; p.B = (int)B; p.T = (int)T; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.dbg = g_attn_variant;
+    p.trace = g_attn_trace;
     p.drop_seed = seed;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -1619,6 +1625,8 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
 }  // namespace
 
 // debug: resident blocks per CU the runtime predicts for the resident forward kernel at sequence length T
+extern "C" int simseg_debug_attn_trace(void* buf) { g_attn_trace = static_cast<unsigned long long*>(buf); return 0; }
+
 extern "C" int simseg_debug_attn_occupancy(int64_t T) {
     int n = -1;
     const int q32 = (int)((T + 31) / 32);
