@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
-    const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
+    const int Tf = p.T, T = MASK ? attn_teff(p, b) : p.T;     // Tf: the tensors' row count; T: the rows this block works on
     const long RS = 3L * p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
     const int nthr = blockDim.x, nw = nthr >> 6;
