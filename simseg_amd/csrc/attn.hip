@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
     const int Tf = p.T, T = attn_teff(p, b);          // Tf: the tensors' row count; T: the rows this block works on
-    if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 3] = wall_clock64();
+    if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 4] = wall_clock64();
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
     const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             landed = true;
-            if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 3 + 1] = wall_clock64();
+            if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 4 + 1] = wall_clock64();
         }
         f32x16 dk[2], dv[2];
 #pragma unroll
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)blockIdx.x * 3 + 2] = wall_clock64(); }
+    if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)blockIdx.x * 4 + 2] = wall_clock64(); p.trace[(long)blockIdx.x * 4 + 3] = p.trace[(long)blockIdx.x * 4 + 2]; }
 }
 
 template <bool DROP>
@@ -1575,6 +1575,253 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 backward, T <= 256 (ViT-B @224, every BERT caption): ONE kernel per (batch, head).  The two resident passes above each
+// recompute S = Q.K^T, dP = dO.V^T and the exponentials, and each reads Q/K/V/dO from HBM (7 tile products and ~300 KB per head at
+// T = 197).  Here wave w owns key tile w for dK / dV (K, V rows and the accumulators in registers, as in the dK/dV pass) AND query
+// tile w for dQ.  It walks the query tiles in the order (w + j) mod n, j = 0..n-1, so at step j every wave holds the dS tile of a
+// DIFFERENT query tile.  dS comes out of the MFMA with the key on the lane; dQ contracts over keys, so the bf16 dS tile takes the
+// transposing trip of the GEMM epilogues anyway - staged [key][query], read back with ds_read_b64_tr_b16 as the B operand of
+// dQ^T = K^T . dS^T - and that staging doubles as the hand-over: after the step's barrier wave w reads the tile that wave (w - j) mod n
+// staged for query tile w, with the K^T fragments of that wave's key tile (transposed reads of the K image), and accumulates dQ in
+// registers in a fixed order (deterministic).  Staging is double-buffered: one barrier per step.  5 tile products and ~200 KB per head.
+// (A first form kept dQ as an fp32 image in LDS with b128 read-add-write per step: 16 KB of LDS traffic per tile, the 13-cycle wide
+// stores made it LDS-bound - 675 us against 610 us for the two passes at B = 512, T = 197.)
+// LDS: [Q rows32 x 128 B][dO][K][staging 2 x waves x 2304 B][lse][delta] = 137 KB at T = 256: one block of up to 8 waves per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int ONE_MAXT = 256;
+constexpr int ONE_TP = 72;               // bytes per staged dS key row (32 queries x 2 B + 8: conflict-free 8-byte writes)
+constexpr int ONE_ST = 32 * ONE_TP;      // one staged tile
+
+__host__ __device__ inline int one_smem(int T) {
+    const int q32 = (T + 31) / 32, rows32 = q32 * 32;
+    return 3 * rows32 * 128 + 2 * q32 * ONE_ST + 2 * rows32 * 4;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, kl = lane & 31;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    const int Tf = p.T;                               // the tensors' row count
+    // (Measured and dropped: persistent blocks walking several heads, started a quarter period apart so that the load / compute / store
+    // phases of different CUs interleave - with one block per head the dispatcher keeps all CUs in the same phase, and a start offset on
+    // the first round is gone by the second.  A block's loads queue behind its previous head's stores, and the loop-invariant addresses
+    // spill: their scratch reloads put s_waitcnt vmcnt(0) between the requests.  686 us against 608 us at B = 512, T = 197.)
+    const int bh_ = blockIdx.x;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = attn_teff(p, b);                    // the rows this block works on
+    if (p.trace && tid == 0) p.trace[(long)bh_ * 4] = wall_clock64();
+    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
+    const bf16_t* obase = static_cast<const bf16_t*>(p.out) + (long)b * Tf * OS + h * 64;
+    const int q32 = (T + 31) / 32, rows32 = q32 * 32;
+    char* ldsQ = lds;
+    char* ldsG = lds + rows32 * 128;
+    char* ldsK = ldsG + rows32 * 128;
+    char* stage = ldsK + rows32 * 128;
+    float* lse_l = reinterpret_cast<float*>(stage + 2 * nw * ONE_ST);
+    float* del_l = lse_l + rows32;
+    const bool active = wave < q32;                   // (a block is launched with one wave per tile of the FULL length)
+    res_copy_rows(base, RS, T, rows32, ldsQ, wave, nw, lane);
+    res_copy_rows(gbase, OS, T, rows32, ldsG, wave, nw, lane);
+    res_copy_rows(base + p.H * 64, RS, T, rows32, ldsK, wave, nw, lane);
+    // every global request of the head goes out before anything waits: the value loads below are consumed after the copies' wait
+    // (an LDS store of a loaded value right here would put a full s_waitcnt in front of the remaining requests: the resident passes
+    // above pay two to three memory round trips that way, most of their 7.6 us 'waiting for copies')
+    // (unconditional requests from clamped addresses, selected afterwards: a request inside a divergent branch also gets its own wait)
+    const float lse_ld = p.lse[((long)b * p.H + h) * Tf + min(tid, T - 1)];
+    // delta = rowsum(dO o O): eight lanes per query row, one 16-byte chunk each; O is requested here, dO is read from its LDS image
+    const int per = nthr >> 3;                        // rows per pass; rows32 <= 4 * per (one wave per 32 rows)
+    bf16x8 o8[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (tid >> 3) + i * per;
+        union { u32x4 v; bf16x8 hh; } uo;
+        uo.v = *reinterpret_cast<const u32x4*>(obase + (long)min(q, T - 1) * OS + (tid & 7) * 8);
+        o8[i] = uo.hh;
+    }
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1, g4 = lane >> 4;
+    const float scale = p.scale_log2e * 0.6931471805599453f;
+    const int arow = kl * 128, asw = qd_swz(kl);
+    const int trow = (4 * h2 + (a16 >> 2)) * 128, tsw = qd_swz(4 * h2 + (a16 >> 2));
+    const int tch = g16 * 2 + ((a16 & 3) >> 1), tsub = ((a16 & 3) & 1) * 8;
+
+    const int key = wave * 32 + kl;                   // this lane's key (dK / dV) and, for dQ, its query
+    const bool kvalid = active && key < T;
+    bf16x8 kr[4], vr[4];         // this lane's K and V row chunks: B operands of S = Q.K^T and dP = dO.V^T (K from its image, below)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        union { u32x4 v; bf16x8 hh; } uv;          // (keys >= T: row T-1, finite; their probabilities are exactly 0)
+        uv.v = *reinterpret_cast<const u32x4*>(base + (long)min(key, T - 1) * RS + 2 * p.H * 64 + (2 * kk + h2) * 8);
+        vr[kk] = uv.hh;
+    }
+    long mk_ = 1;                // the last request: a wait the compiler attaches to this (uniform) branch coincides with the one below
+    if (p.mask) mk_ = p.mask[(long)b * Tf + min(key, T - 1)];
+    // dS staging: write [key = kl][4 queries 8 g + 4 h2 ..]; read back queries (g4 & 1) * 16 + a16 = lane % 32, key slots of MFMA step s2:
+    // keys 16 s2 + 4 (lane / 32) + {0..3} (low half) and + 8 (high half) - the slot order of the transposed K fragments
+    const int st_w = kl * ONE_TP + (4 * h2) * 2;
+    const int st_r = (4 * (g4 >> 1) + (a16 >> 2)) * ONE_TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+
+    f32x16 dk[2], dv[2], dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; dq[i][r] = 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < rows32) lse_l[tid] = tid < T ? lse_ld : 1e30f;          // (one wave per 32 rows: rows32 <= blockDim.x); 1e30 -> P = 0 for padded queries
+    const float kb_ = (kvalid && mk_ != 0) ? 0.f : NEG;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (tid >> 3) + i * per;
+        float d = 0.f;
+        if (q < T) {
+            const bf16x8 g8 = ld_bf16x8(ldsG + q * 128 + (((tid & 7) ^ qd_swz(q)) << 4));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)o8[i][e] * (float)g8[e];
+        }
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if ((tid & 7) == 0 && q < rows32) del_l[q] = d;              // (rows >= T: 0)
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kr[kk] = ld_bf16x8(ldsK + (active ? wave * 32 * 128 : 0) + arow + (((2 * kk + h2) ^ asw) << 4));
+    __syncthreads();
+    if (p.trace && tid == 0) p.trace[(long)bh_ * 4 + 1] = wall_clock64();
+#pragma unroll 1
+    for (int j = 0; j < q32; ++j) {
+        char* stj = stage + (j & 1) * nw * ONE_ST;
+        if (active) {
+            int qt = wave + j;
+            if (qt >= q32) qt -= q32;
+            const int q0 = qt * 32;
+            const char* cq = ldsQ + q0 * 128;
+            const char* cg = ldsG + q0 * 128;
+            bf16x8 aq[4], ag[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = arow + (((2 * kk + h2) ^ asw) << 4);
+                aq[kk] = ld_bf16x8(cq + off);
+                ag[kk] = ld_bf16x8(cg + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
+            }
+            // the rest in two halves of 16 query rows (MFMA step s2): lse / delta of the rows, the transposed dO / Q fragments, the
+            // exponentials, then dV^T[d][key] += dO^T[d][q] . P[q][key] and dK^T[d][key] += Q^T[d][q] . dS[q][key].  (All 32 rows at
+            // once held 32 more registers at the peak: spills, and a spilled V fragment puts scratch waits into the prologue.)
+            char* mine = stj + wave * ONE_ST + st_w;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float4 l4[2], d4[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    l4[i] = *reinterpret_cast<const float4*>(lse_l + q0 + 8 * (2 * s2 + i) + 4 * h2);
+                    d4[i] = *reinterpret_cast<const float4*>(del_l + q0 + 8 * (2 * s2 + i) + 4 * h2);
+                }
+                bf16x8 gf[2], qf[2];                          // index db
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int ro = (16 * s2) * 128 + trow;
+                    const int ca = (((db * 4 + tch) ^ tsw) << 4) + tsub, cb = (((db * 4 + tch) ^ tsw ^ 4) << 4) + tsub;
+                    gf[db] = tr_frag2(cg + ro + ca, cg + ro + 8 * 128 + cb);      // dO^T fragment: [d][q-slots]
+                    qf[db] = tr_frag2(cq + ro + ca, cq + ro + 8 * 128 + cb);      // Q^T fragment
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // lane: key column kl, rows q = (r%4) + 8*(r/4) + 4*h2
+                bf16x8 pf, df;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s2 + e;
+                    const float lq = reinterpret_cast<const float*>(&l4[e >> 2])[e & 3];
+                    const float dq_ = reinterpret_cast<const float*>(&d4[e >> 2])[e & 3];
+                    const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lq, 0.f));
+                    float keep = 1.f;
+                    if (DROP) {
+                        const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
+                        const unsigned idx = ((unsigned)bh_ * Tf + (q0 + qq)) * Tf + key;
+                        keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
+                    }
+                    pf[e] = (bf16_t)(pr * keep);                                   // dropped probabilities feed dV
+                    df[e] = (bf16_t)(pr * (dp[r] * keep - dq_) * scale);          // dS feeds dK and dQ
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {                        // the same bf16 dS, staged [key][query] for the wave that owns query tile qt
+                    union { bf16_t hh[4]; uint2 u; } w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w.hh[e] = df[4 * g + e];
+                    *reinterpret_cast<uint2*>(mine + (8 * (2 * s2 + g)) * 2) = w.u;
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[db], pf, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[db], df, dk[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // dQ^T[d][q] += K^T[d][keys of tile kt] . dS^T[keys][q] for this wave's query tile: the tile wave kt staged in this step
+            int kt = wave - j;
+            if (kt < 0) kt += q32;
+            const char* ck = ldsK + kt * 32 * 128;
+            const char* src = stj + kt * ONE_ST + st_r;
+            bf16x8 kf[4];                                     // index s2 * 2 + db
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ro = (16 * (i >> 1)) * 128 + trow;
+                const int ca = ((((i & 1) * 4 + tch) ^ tsw) << 4) + tsub, cb = ((((i & 1) * 4 + tch) ^ tsw ^ 4) << 4) + tsub;
+                kf[i] = tr_frag2(ck + ro + ca, ck + ro + 8 * 128 + cb);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                union { struct { s16x4 lo, hi; } hq; bf16x8 v; } u;
+                u.hq.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + s2 * 16 * ONE_TP));
+                u.hq.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + s2 * 16 * ONE_TP + 8 * ONE_TP));
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], u.v, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    if (p.trace && tid == 0) p.trace[(long)bh_ * 4 + 2] = wall_clock64();
+    // accumulators (transposed): column = this lane's key (dK, dV) / query (dQ), rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
+    if (kvalid) {
+        bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)key * RS;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                store_bf16x4(drow + d, dq[db][4 * r4], dq[db][4 * r4 + 1], dq[db][4 * r4 + 2], dq[db][4 * r4 + 3]);
+                store_bf16x4(drow + p.H * 64 + d, dk[db][4 * r4], dk[db][4 * r4 + 1], dk[db][4 * r4 + 2], dk[db][4 * r4 + 3]);
+                store_bf16x4(drow + 2 * p.H * 64 + d, dv[db][4 * r4], dv[db][4 * r4 + 1], dv[db][4 * r4 + 2], dv[db][4 * r4 + 3]);
+            }
+    }
+    if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)bh_ * 4 + 3] = wall_clock64(); }
+}
+
+template <bool DROP>
+int launch_bwd_one(const AttnParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_one_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, one_smem(ONE_MAXT));
+        if (e != hipSuccess) return simseg_set_error("attention_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const int q32 = (p.T + 31) / 32;
+    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)(p.B * p.H)), dim3(q32 * 64), one_smem(p.T), stream, p);
+    return 0;
 }
 
 template <bool DROP>
@@ -1718,7 +1965,9 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     if (!resident)       // (the resident dQ kernel forms delta itself)
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                            (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
-    if (resident) {
+    if (resident && T <= ONE_MAXT && g_attn_variant != 3) {       // (variant 3: the two resident passes, for A/B runs)
+        if (int rc = p.drop_thresh ? launch_bwd_one<true>(p, s) : launch_bwd_one<false>(p, s)) return rc;
+    } else if (resident) {
         if (int rc = p.drop_thresh ? launch_bwd_res<true>(p, s) : launch_bwd_res<false>(p, s)) return rc;
     } else if (p.drop_thresh) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
