@@ -1603,14 +1603,24 @@ __host__ __device__ inline int one_smem(int T) {
 template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, kl = lane & 31;
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int Tf = p.T;                               // the tensors' row count
-    // (Measured and dropped: persistent blocks walking several heads, started a quarter period apart so that the load / compute / store
-    // phases of different CUs interleave - with one block per head the dispatcher keeps all CUs in the same phase, and a start offset on
-    // the first round is gone by the second.  A block's loads queue behind its previous head's stores, and the loop-invariant addresses
-    // spill: their scratch reloads put s_waitcnt vmcnt(0) between the requests.  686 us against 608 us at B = 512, T = 197.)
-    const int bh_ = blockIdx.x;
+    const int nitems = p.B * p.H;
+    // PERSISTENT blocks (one per CU at T = 197), each walking its share of the heads.  With one block per head the dispatcher keeps all
+    // CUs in the same phase - all load (HBM-bound, matrix cores idle), all compute (HBM idle), all store - and leaves ~2.7 us between a
+    // block's end and its successor's start; a start offset on the first round is gone by the second.  Persistent blocks started a
+    // quarter period apart keep their offsets, so the phases of different CUs interleave for the whole launch.  The per-head address
+    // arithmetic must stay inside the loop (an opaque lane id): hoisted, it spills, and scratch reloads put waits between the requests.
+    if (p.dbg != 5 && nitems >= 4 * (int)gridDim.x) {
+        const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 3) * (2 * Tf));      // 10 ns ticks
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll 1
+    for (int bh_ = blockIdx.x; bh_ < nitems; bh_ += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, h2 = lane >> 5, kl = lane & 31;
     const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = attn_teff(p, b);                    // the rows this block works on
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4] = wall_clock64();
@@ -1795,20 +1805,42 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         }
     }
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4 + 2] = wall_clock64();
-    // accumulators (transposed): column = this lane's key (dK, dV) / query (dQ), rows d = db*32 + (r%4) + 8*(r/4) + 4*h2
-    if (kvalid) {
-        bf16_t* drow = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)key * RS;
+    // accumulators (transposed): column = this lane's key (dK, dV) / query (dQ), rows d = db*32 + (r%4) + 8*(r/4) + 4*h2.  Stored from
+    // there, a wave-instruction writes 32 separate 16-byte segments (5 376 segments per head: 3.5 us of the per-block timeline).  Each
+    // tile goes through the wave's share of the staging area instead - the lane writes its row's eight 8-byte pieces, the wave reads the
+    // tile back 16 bytes per lane, row-contiguous - and leaves as whole 128-byte rows, eight per instruction.
+    __syncthreads();             // every wave has left the last step: the staging area is free
+    if (active) {
+        constexpr int OP = 144;                       // bytes per staged row (128 + 16: 16-byte aligned rows)
+        char* ob = stage + wave * (2 * ONE_ST);       // 32 x 144 = 4 608 B
+        bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)(wave * 32) * RS;
+        auto put = [&](const f32x16 (&acc)[2], int sel) {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = db * 32 + 8 * r4 + 4 * h2;
-                store_bf16x4(drow + d, dq[db][4 * r4], dq[db][4 * r4 + 1], dq[db][4 * r4 + 2], dq[db][4 * r4 + 3]);
-                store_bf16x4(drow + p.H * 64 + d, dk[db][4 * r4], dk[db][4 * r4 + 1], dk[db][4 * r4 + 2], dk[db][4 * r4 + 3]);
-                store_bf16x4(drow + 2 * p.H * 64 + d, dv[db][4 * r4], dv[db][4 * r4 + 1], dv[db][4 * r4 + 2], dv[db][4 * r4 + 3]);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    union { bf16_t hh[4]; uint2 u; } w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w.hh[e] = (bf16_t)acc[db][4 * r4 + e];
+                    *reinterpret_cast<uint2*>(ob + kl * OP + (db * 32 + 8 * r4 + 4 * h2) * 2) = w.u;
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * OP + (lane & 7) * 16);
+                if (wave * 32 + row < T) *reinterpret_cast<u32x4*>(dbase + (long)row * RS + sel * p.H * 64 + (lane & 7) * 8) = v;
             }
+            __builtin_amdgcn_wave_barrier();
+        };
+        put(dq, 0);
+        put(dk, 1);
+        put(dv, 2);
     }
     if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)bh_ * 4 + 3] = wall_clock64(); }
+    __syncthreads();             // the images and the staging are free for the next head's copies
+    }
 }
 
 template <bool DROP>
@@ -1820,7 +1852,14 @@ int launch_bwd_one(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const int q32 = (p.T + 31) / 32;
-    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)(p.B * p.H)), dim3(q32 * 64), one_smem(p.T), stream, p);
+    // persistent blocks: as many as are resident at once (LDS: 160 KiB per CU; registers: 8 waves of 256 VGPRs per CU)
+    const int smem = one_smem(p.T);
+    int per_cu = (160 * 1024) / (smem + 1280);
+    if (per_cu > 8 / q32) per_cu = 8 / q32;
+    if (per_cu < 1) per_cu = 1;
+    long grid = 256L * per_cu;
+    if (grid > (long)p.B * p.H || p.dbg == 6) grid = (long)p.B * p.H;          // (variant 6: one block per head, for A/B runs)
+    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)grid), dim3(q32 * 64), smem, stream, p);
     return 0;
 }
 
