@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float* kb_all = reinterpret_cast<float*>(ldsV + rows8 * 128);
 
     // K rows first (the first MFMAs need only K), then V rows; rows past T re-read row T-1
-    for (int piece = (p.dbg == 2 ? 2 * np : wave); piece < 2 * np; piece += nw) {
+    for (int piece = (p.dbg == 102 ? 2 * np : wave); piece < 2 * np; piece += nw) {
         const int isv = piece >= np;
         const int pp = isv ? piece - np : piece;
         const int r = pp * 8 + (lane >> 3);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
             }
         };
-        if (p.dbg != 3) {
+        if (p.dbg != 103) {
             for (int it = 0; it < nt - 1; ++it) tile(it, std::false_type{});
             tile(nt - 1, std::true_type{});            // (a full last tile goes through the masked form too: same result)
         }
@@ -1603,24 +1603,18 @@ __host__ __device__ inline int one_smem(int T) {
 template <bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, kl = lane & 31;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int Tf = p.T;                               // the tensors' row count
-    const int nitems = p.B * p.H;
-    // PERSISTENT blocks (one per CU at T = 197), each walking its share of the heads.  With one block per head the dispatcher keeps all
-    // CUs in the same phase - all load (HBM-bound, matrix cores idle), all compute (HBM idle), all store - and leaves ~2.7 us between a
-    // block's end and its successor's start; a start offset on the first round is gone by the second.  Persistent blocks started a
-    // quarter period apart keep their offsets, so the phases of different CUs interleave for the whole launch.  The per-head address
-    // arithmetic must stay inside the loop (an opaque lane id): hoisted, it spills, and scratch reloads put waits between the requests.
-    if (p.dbg != 5 && nitems >= 4 * (int)gridDim.x) {
-        const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 3) * (2 * Tf));      // 10 ns ticks
-        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
-    }
-#pragma unroll 1
-    for (int bh_ = blockIdx.x; bh_ < nitems; bh_ += gridDim.x) {
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, h2 = lane >> 5, kl = lane & 31;
+    // Measured and dropped (tools/attn_bwd_ab.py, tools/dbg_attn_trace.py; B = 512, T = 197):
+    //  - persistent blocks walking several heads, started a quarter period apart.  With one block per head the dispatcher keeps the CUs
+    //    in step (all load, all compute, all store; a start offset on the first round is gone by the second); persistent blocks do keep
+    //    their offsets, but a head's copies take ~5 us either way - 125 KB at the ~23 GB/s that one CU's outstanding requests sustain,
+    //    not the HBM - so nothing is gained (481 vs 466 us).  (Their loop-invariant address arithmetic must also be kept from being
+    //    hoisted: it spills, and scratch reloads put s_waitcnt vmcnt(0) between the requests - 686 us.)
+    //  - an L2 prefetch of the next head through global_load_lds into a landing area nobody reads: the wait drops from 5.3 to 4.0 us,
+    //    the tile loop grows from 10.0 to 13.3 us (LDS write traffic of the landing copies).
+    const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = attn_teff(p, b);                    // the rows this block works on
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4] = wall_clock64();
@@ -1839,8 +1833,6 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         put(dv, 2);
     }
     if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)bh_ * 4 + 3] = wall_clock64(); }
-    __syncthreads();             // the images and the staging are free for the next head's copies
-    }
 }
 
 template <bool DROP>
@@ -1852,14 +1844,7 @@ int launch_bwd_one(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const int q32 = (p.T + 31) / 32;
-    // persistent blocks: as many as are resident at once (LDS: 160 KiB per CU; registers: 8 waves of 256 VGPRs per CU)
-    const int smem = one_smem(p.T);
-    int per_cu = (160 * 1024) / (smem + 1280);
-    if (per_cu > 8 / q32) per_cu = 8 / q32;
-    if (per_cu < 1) per_cu = 1;
-    long grid = 256L * per_cu;
-    if (grid > (long)p.B * p.H || p.dbg == 6) grid = (long)p.B * p.H;          // (variant 6: one block per head, for A/B runs)
-    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)grid), dim3(q32 * 64), smem, stream, p);
+    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)(p.B * p.H)), dim3(q32 * 64), one_smem(p.T), stream, p);
     return 0;
 }
 
@@ -1888,7 +1873,9 @@ int launch_bwd_res(const AttnParams& p, hipStream_t stream) {
 int attn_waves_per_block(int q32) { return q32 <= 4 ? q32 : 4; }
 
 thread_local unsigned long long* g_attn_trace = nullptr;
-thread_local int g_attn_variant = 0;   // tests / benchmarks (thread-local selector): 1 = always the streaming (ring) kernels
+thread_local int g_attn_variant = 0;   // tests / benchmarks (thread-local selector): 1 = always the streaming (ring) kernels, 3 = backward as the two
+                                       // resident passes, 4 = resident forward for every T <= 256; 102 / 103 = forward ablations (WRONG results:
+                                       // no operand copies / no tile loop - tools/dbg_attn_res.py only)
 
 int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, int64_t T, int64_t H, float scale,
                 uint64_t seed, float drop_p) {

@@ -44,7 +44,8 @@ def set_gemm_variant(v):
 
 
 def set_attention_variant(v):
-    """0 auto (bf16 sequences of <= 256 tokens on the resident kernels), 1 = always the streaming ring kernels (tests / benchmarks only)."""
+    """0 auto (bf16 sequences of <= 256 tokens on the resident kernels, their backward as one kernel), 1 = always the streaming ring
+    kernels, 3 = backward as the two resident passes (tests / benchmarks only)."""
     _VARIANT["attention"] = int(v)
     _push_variant("attention")
 

@@ -27,7 +27,7 @@ print("predicted resident blocks per CU:", {T: raw("simseg_debug_attn_occupancy"
 for B, T, H in ((512, 197, 12), (512, 77, 12), (512, 25, 12)):
     qkv = torch.randn(B, T, 3 * H * 64, device="cuda", generator=g).bfloat16()
     row = [f"B={B} T={T}"]
-    for v, name in ((4, "resident"), (2, "no-copy"), (3, "no-loop"), (1, "ring")):
+    for v, name in ((4, "resident"), (102, "no-copy"), (103, "no-loop"), (1, "ring")):
         ops.set_attention_variant(v)
         row.append(f"{name} {timeit(lambda: ops.attention_fwd(qkv, H, None, save_lse=True)) * 1e3:.1f} us")
     ops.set_attention_variant(0)
