@@ -1677,8 +1677,9 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; dq[i][r] = 0.f; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < rows32) lse_l[tid] = tid < T ? lse_ld : 1e30f;          // (one wave per 32 rows: rows32 <= blockDim.x); 1e30 -> P = 0 for padded queries
+    if (tid < rows32) lse_l[tid] = tid < T ? -lse_ld : -1e30f;        // MINUS lse (one wave per 32 rows: rows32 <= blockDim.x); -1e30 -> P = 0 for padded queries
     const float kb_ = (kvalid && mk_ != 0) ? 0.f : NEG;
+    const float kinit = kb_ / p.scale_log2e;          // S accumulators start here: fma(S, c, -lse) then carries the key bias
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1690,10 +1691,12 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
             for (int e = 0; e < 8; ++e) d += (float)o8[i][e] * (float)g8[e];
         }
         d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-        if ((tid & 7) == 0 && q < rows32) del_l[q] = d;              // (rows >= T: 0)
+        if ((tid & 7) == 0 && q < rows32) del_l[q] = -d;             // MINUS delta (rows >= T: 0)
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) kr[kk] = ld_bf16x8(ldsK + (active ? wave * 32 * 128 : 0) + arow + (((2 * kk + h2) ^ asw) << 4));
+    // (the dropout instantiation re-reads these four fragments from the K image in every step instead of holding them: its hash
+    // arithmetic needs the 16 registers - spilled, a V fragment's scratch round trip sits in the prologue and in every step)
     __syncthreads();
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4 + 1] = wall_clock64();
 #pragma unroll 1
@@ -1711,11 +1714,26 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                 const int off = arow + (((2 * kk + h2) ^ asw) << 4);
                 aq[kk] = ld_bf16x8(cq + off);
                 ag[kk] = ld_bf16x8(cg + off);
+                if (DROP) kr[kk] = ld_bf16x8(ldsK + wave * 32 * 128 + off);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The accumulators start from the per-lane key bias (S) and from minus delta of their query rows (dP, straight from LDS), so the
+            // element work below is x = fma(S, c, -lse), min, exp2, one multiply and the conversions: the exponential stage is VALU-bound
+            // (v_exp_f32 issues at a quarter rate) and runs beside only one other wave's MFMAs.  The softmax scale of dS is applied to the
+            // dK / dQ accumulators once, at the end.
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) s[r] = kinit;
+            if (DROP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 nd = *reinterpret_cast<const float4*>(del_l + q0 + 8 * i + 4 * h2);
+                    dp[4 * i] = nd.x; dp[4 * i + 1] = nd.y; dp[4 * i + 2] = nd.z; dp[4 * i + 3] = nd.w;
+                }
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
@@ -1731,7 +1749,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     l4[i] = *reinterpret_cast<const float4*>(lse_l + q0 + 8 * (2 * s2 + i) + 4 * h2);
-                    d4[i] = *reinterpret_cast<const float4*>(del_l + q0 + 8 * (2 * s2 + i) + 4 * h2);
+                    if (DROP) d4[i] = *reinterpret_cast<const float4*>(del_l + q0 + 8 * (2 * s2 + i) + 4 * h2);
                 }
                 bf16x8 gf[2], qf[2];                          // index db
 #pragma unroll
@@ -1747,9 +1765,8 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * s2 + e;
-                    const float lq = reinterpret_cast<const float*>(&l4[e >> 2])[e & 3];
-                    const float dq_ = reinterpret_cast<const float*>(&d4[e >> 2])[e & 3];
-                    const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * p.scale_log2e + kb_ - lq, 0.f));
+                    const float nlq = reinterpret_cast<const float*>(&l4[e >> 2])[e & 3];
+                    const float pr = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(s[r], p.scale_log2e, nlq), 0.f));
                     float keep = 1.f;
                     if (DROP) {
                         const int qq = (r & 3) + 8 * (r >> 2) + 4 * h2;
@@ -1757,7 +1774,8 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                         keep = dropout_keep32(seed_fold(p.drop_seed), idx, p.drop_thresh) ? p.drop_scale : 0.f;
                     }
                     pf[e] = (bf16_t)(pr * keep);                                   // dropped probabilities feed dV
-                    df[e] = (bf16_t)(pr * (dp[r] * keep - dq_) * scale);          // dS feeds dK and dQ
+                    if (DROP) df[e] = (bf16_t)(pr * (dp[r] * keep + reinterpret_cast<const float*>(&d4[e >> 2])[e & 3]));
+                    else df[e] = (bf16_t)(pr * dp[r]);                             // dS / scale feeds dK and dQ
                 }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {                        // the same bf16 dS, staged [key][query] for the wave that owns query tile qt
@@ -1808,14 +1826,14 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         constexpr int OP = 144;                       // bytes per staged row (128 + 16: 16-byte aligned rows)
         char* ob = stage + wave * (2 * ONE_ST);       // 32 x 144 = 4 608 B
         bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)(wave * 32) * RS;
-        auto put = [&](const f32x16 (&acc)[2], int sel) {
+        auto put = [&](const f32x16 (&acc)[2], int sel, float mul) {
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     union { bf16_t hh[4]; uint2 u; } w;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w.hh[e] = (bf16_t)acc[db][4 * r4 + e];
+                    for (int e = 0; e < 4; ++e) w.hh[e] = (bf16_t)(acc[db][4 * r4 + e] * mul);
                     *reinterpret_cast<uint2*>(ob + kl * OP + (db * 32 + 8 * r4 + 4 * h2) * 2) = w.u;
                 }
             __builtin_amdgcn_wave_barrier();
@@ -1828,9 +1846,9 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
             }
             __builtin_amdgcn_wave_barrier();
         };
-        put(dq, 0);
-        put(dk, 1);
-        put(dv, 2);
+        put(dq, 0, scale);
+        put(dk, 1, scale);
+        put(dv, 2, 1.f);
     }
     if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)bh_ * 4 + 3] = wall_clock64(); }
 }

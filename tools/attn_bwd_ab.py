@@ -25,21 +25,27 @@ def timeit(fn, iters=20):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     H = 12
-    for name, B, T, masked in (("vitb_224", 512, 197, False), ("bert_77", 512, 77, True), ("t224", 64, 224, False), ("t33", 64, 33, False)):
+    for name, B, T, masked, drop in (("vitb_224", 512, 197, False, 0.0), ("bert_77", 512, 77, True, 0.0), ("bert_77_dropout", 512, 77, True, 0.1),
+                                      ("bert_77_packed", 512, 77, True, 0.1), ("t224", 64, 224, False, 0.0), ("t33", 64, 33, False, 0.0)):
         qkv = torch.randn(B, T, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
         mask = None
         if masked:
             lens = torch.randint(5, T + 1, (B,), device="cuda", generator=g)
             mask = (torch.arange(T, device="cuda")[None] < lens[:, None]).long()
-        o, lse = ops.attention_fwd(qkv, H, mask, save_lse=True)
+        kw = dict(drop_seed=1234, drop_p=drop, skip_padded_rows=name.endswith("packed"))
+        o, lse = ops.attention_fwd(qkv, H, mask, save_lse=True, **kw)
         do = torch.randn_like(o)
+        if mask is not None:
+            do = do * mask[:, :, None].to(do.dtype)       # the caller contract of skip_padded_rows: no gradient arrives on padded rows
         res = {}
         for v in (0, 3):
             ops.set_attention_variant(v)
-            res[v] = ops.attention_bwd(qkv, o, do, lse, H, mask).float()
-            us = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, H, mask))
+            res[v] = ops.attention_bwd(qkv, o, do, lse, H, mask, **kw).float()
+            us = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, H, mask, **kw))
             print(f"{name} B={B} T={T} variant={v}: {us:.1f} us", flush=True)
         ops.set_attention_variant(0)
+        if mask is not None:
+            res = {k: r * mask[:, :, None] for k, r in res.items()}
         d = (res[0] - res[3]).abs()
         print(f"   max |one - two| = {d.max().item():.3e} (max |two| = {res[3].abs().max().item():.3e}), elements differing: {(d > 0).float().mean().item():.4f}")
 
