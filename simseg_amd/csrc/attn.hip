@@ -769,10 +769,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)((isv ? ldsV : ldsK) + pp * 1024), 16, 0, 0);
     }
-    if (MASK) {
-        for (int key = tid; key < nt * KT; key += nthr)
-            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * Tf + key] != 0)) ? 0.f : NEG;
-    }
     // this wave's query tiles: wave, wave + nw (T <= 256 and nw = min(4, q32): at most two).  The first tile's Q rows are fetched
     // with the K / V copies; the second tile's replace them as soon as the first pass has formed its last scores.
     bf16x8 qr[4];
@@ -780,13 +776,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int q = qt * 32 + ql;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            union { u32x4 v; bf16x8 hh; } u;
-            u.v = (u32x4){0u, 0u, 0u, 0u};
-            if (q < T) u.v = *reinterpret_cast<const u32x4*>(base + (long)q * RS + (2 * kk + h2) * 8);
+            union { u32x4 v; bf16x8 hh; } u;      // (queries >= T: row T-1, never stored - an unconditional request needs no wait of its own)
+            u.v = *reinterpret_cast<const u32x4*>(base + (long)min(q, T - 1) * RS + (2 * kk + h2) * 8);
             qr[kk] = u.hh;
         }
     };
     load_q(wave);
+    if (MASK) {      // after the Q requests: storing a loaded value to LDS waits for everything requested before it
+        for (int key = tid; key < nt * KT; key += nthr)
+            kb_all[key] = (key < T && (!p.mask || p.mask[(long)b * Tf + key] != 0)) ? 0.f : NEG;
+    }
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const int krow = ql * 128, ksw = k_swz(ql);
     const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);

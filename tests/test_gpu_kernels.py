@@ -606,6 +606,35 @@ def test_attention_edge_lengths(ops, T):
     _close(dqkv, x.grad, 2e-2, f"attention bwd T={T}")
 
 
+@pytest.mark.parametrize("T", [33, 77, 197, 224, 256])
+def test_attention_bwd_one_kernel_vs_two_passes(ops, T):
+    """bf16 backward for T <= 256: the one-kernel form (default) against the two resident passes (variant 3) and the fp32 reference, with a
+    ragged key mask and dropout; the one-kernel form hands dS tiles between waves in a fixed order, so two runs are bit-identical."""
+    B, H = 3, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T + 11, scale=1.2, dtype=torch.bfloat16)
+    dout = _rand(B, T, H * 64, seed=T + 12, dtype=torch.bfloat16)
+    mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate((T, max(1, T // 3), 1)):
+        mask[b, :n] = 1
+    mask = mask.cuda()
+    for m, p in ((None, 0.0), (mask, 0.0), (mask, 0.1)):
+        out, lse = ops.attention_fwd(qkv, H, m, save_lse=True, drop_seed=9, drop_p=p)
+        one = ops.attention_bwd(qkv, out, dout, lse, H, m, drop_seed=9, drop_p=p)
+        again = ops.attention_bwd(qkv, out, dout, lse, H, m, drop_seed=9, drop_p=p)
+        assert torch.equal(one, again)
+        ops.set_attention_variant(3)
+        try:
+            two = ops.attention_bwd(qkv, out, dout, lse, H, m, drop_seed=9, drop_p=p)
+        finally:
+            ops.set_attention_variant(0)
+        _close(one, two.float(), 6e-3, f"one kernel vs two passes T={T} mask={m is not None} p={p}")
+        if p == 0.0:
+            x = qkv.float().requires_grad_(True)
+            _attn_ref(x, H, m, 0.125).backward(dout.float())
+            _close(two, x.grad, 2e-2, f"two-pass attention bwd T={T}")
+            _close(one, x.grad, 2e-2, f"one-kernel attention bwd T={T}")
+
+
 def test_attention_masked_length_limit(ops):
     qkv = _rand(1, 1100, 3 * 64, seed=1, dtype=torch.bfloat16)
     mask = torch.ones(1, 1100, dtype=torch.long, device="cuda")
