@@ -121,9 +121,13 @@ int simseg_debug_gemm_stagger(int ticks);
 int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B, int64_t T,
                          int64_t H, float scale, uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
 /* Backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse, all in `dtype` (0 = fp32: the exact mode of a non-AMP run,
- * simseg/core/hooks/optimizer.py:76-77; 1 = bf16); delta[B,H,T] is caller-provided fp32 scratch. */
+ * simseg/core/hooks/optimizer.py:76-77; 1 = bf16).  workspace: caller-provided fp32 scratch of simseg_attention_bwd_workspace_bytes(B, T, H).
+ * dqkv_colsum (optional, [3*H*64] fp32) += column sums of dqkv over all B*T rows: the bias gradient of the q/k/v projection (timm
+ * Attention.qkv.bias, HF BertSelfAttention.{query,key,value}.bias), formed inside the one-kernel bf16 backward (T <= 256) and by a
+ * column-sum pass over dqkv otherwise. */
+int64_t simseg_attention_bwd_workspace_bytes(int64_t B, int64_t T, int64_t H);
 int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
-                         float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
+                         float* workspace, void* dqkv, float* dqkv_colsum, int dtype, int64_t B, int64_t T, int64_t H, float scale,
                          uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
 
 /* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).

@@ -29,6 +29,7 @@ struct AttnParams {
     int dbg;            // resident kernels, benchmarking only: 2 = skip the K/V copy, 3 = skip the tile loop
     unsigned long long* trace;   // debugging (simseg_debug_attn_trace): per block {start, operands landed, end} wall-clock stamps
     int pack;           // resident kernels: rows past the last unmasked key of a sequence are neither read nor written (see attn_teff)
+    float* colsum_ws;   // one-kernel backward: [B][3*H*64] per-sequence column sums of dqkv (the qkv bias gradient before the fold over B), or null
 };
 
 // online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
@@ -1825,6 +1826,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         constexpr int OP = 144;                       // bytes per staged row (128 + 16: 16-byte aligned rows)
         char* ob = stage + wave * (2 * ONE_ST);       // 32 x 144 = 4 608 B
         bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)(wave * 32) * RS;
+        float* cpart = reinterpret_cast<float*>(ldsQ);                 // [wave][3][64] column sums (the operand images are free by now)
         auto put = [&](const f32x16 (&acc)[2], int sel, float mul) {
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -1843,11 +1845,32 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * OP + (lane & 7) * 16);
                 if (wave * 32 + row < T) *reinterpret_cast<u32x4*>(dbase + (long)row * RS + sel * p.H * 64 + (lane & 7) * 8) = v;
             }
+            if (p.colsum_ws) {       // lane = one of the tile's 64 columns: the sum of its (rounded, as stored) valid rows
+                const int nrow = min(32, T - wave * 32);
+                float c0_ = 0.f, c1_ = 0.f, c2_ = 0.f, c3_ = 0.f;
+                const bf16_t* col = reinterpret_cast<const bf16_t*>(ob) + lane;
+                int r = 0;
+                for (; r + 4 <= nrow; r += 4) {
+                    c0_ += (float)col[(r + 0) * (OP / 2)]; c1_ += (float)col[(r + 1) * (OP / 2)];
+                    c2_ += (float)col[(r + 2) * (OP / 2)]; c3_ += (float)col[(r + 3) * (OP / 2)];
+                }
+                for (; r < nrow; ++r) c0_ += (float)col[r * (OP / 2)];
+                cpart[(wave * 3 + sel) * 64 + lane] = (c0_ + c1_) + (c2_ + c3_);
+            }
             __builtin_amdgcn_wave_barrier();
         };
         put(dq, 0, scale);
         put(dk, 1, scale);
         put(dv, 2, 1.f);
+    }
+    if (p.colsum_ws) {           // this head's 3 x 64 column sums over its sequence: waves in a fixed order, plain stores (folded over B by the caller)
+        __syncthreads();
+        for (int i = tid; i < 192; i += nthr) {
+            const float* cpart = reinterpret_cast<const float*>(ldsQ);
+            float c = 0.f;
+            for (int w = 0; w < q32; ++w) c += cpart[(w * 3 + i / 64) * 64 + (i & 63)];
+            p.colsum_ws[((long)b * 3 + i / 64) * (p.H * 64) + h * 64 + (i & 63)] = c;
+        }
     }
     if (p.trace && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[(long)bh_ * 4 + 3] = wall_clock64(); }
 }
@@ -1975,13 +1998,20 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
 
 // backward: dqkv[B,T,3,H,64] from qkv, ctx (forward output), dctx, lse; delta[B,H,T] is caller-provided scratch.  All tensors in
 // `dtype` (0 = fp32 exact mode, 1 = bf16).
+extern "C" int64_t simseg_attention_bwd_workspace_bytes(int64_t B, int64_t T, int64_t H) {
+    return (B * H * T + B * 3 * H * 64) * (int64_t)sizeof(float);      // delta[B,H,T] + per-sequence column sums [B, 3*H*64]
+}
+
+extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream);
+
 extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
-                                    float* delta, void* dqkv, int dtype, int64_t B, int64_t T, int64_t H, float scale,
+                                    float* workspace, void* dqkv, float* dqkv_colsum, int dtype, int64_t B, int64_t T, int64_t H, float scale,
                                     uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream) {
+    float* delta = workspace;
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
     p.pack = skip_padded_rows && key_mask && dtype == 1 && T <= RES_MAXT;
-    SS_CHECK(out && dout && lse && delta && dqkv, "attention_bwd: null pointer");
+    SS_CHECK(out && dout && lse && workspace && dqkv, "attention_bwd: null pointer");
     SS_CHECK(dtype == 0 || dtype == 1, "attention_bwd: dtype must be 0 (fp32) or 1 (bf16)");
     p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta; p.dqkv = dqkv;
     hipStream_t s = (hipStream_t)stream;
@@ -1998,6 +2028,7 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
             hipLaunchKernelGGL((attn_bwd_f32_kernel<true, false>), grid, dim3(nw * 64), 0, s, p);
         }
         SS_LAUNCH_CHECK("attention_bwd (fp32)");
+        if (dqkv_colsum) return simseg_colsum_accum(dqkv, 0, dqkv_colsum, B * T, 3 * H * 64, 3 * H * 64, stream);
         return 0;
     }
     const long groups = B * T * H;
@@ -2009,8 +2040,16 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
                            (const bf16_t*)dout, delta, (int)B, (int)T, (int)H);
     if (resident && T <= ONE_MAXT && g_attn_variant != 3) {       // (variant 3: the two resident passes, for A/B runs)
+        // the qkv bias gradient rides along: per-sequence column sums from the kernel, folded over the batch by the column-sum kernel
+        // ([B, 3*H*64] fp32: 4.7 MB at the training shape instead of a pass over the 465 MB of dqkv)
+        p.colsum_ws = dqkv_colsum ? workspace + B * H * T : nullptr;
         if (int rc = p.drop_thresh ? launch_bwd_one<true>(p, s) : launch_bwd_one<false>(p, s)) return rc;
-    } else if (resident) {
+        SS_LAUNCH_CHECK("attention_bwd");
+        if (dqkv_colsum) return simseg_colsum_accum(p.colsum_ws, 0, dqkv_colsum, B, 3 * H * 64, 3 * H * 64, stream);
+        return 0;
+    }
+    if (dqkv_colsum && p.pack) hipMemsetAsync(dqkv, 0, (size_t)B * T * 3 * H * 64 * 2, s);     // (rows these kernels leave untouched are summed below)
+    if (resident) {
         if (int rc = p.drop_thresh ? launch_bwd_res<true>(p, s) : launch_bwd_res<false>(p, s)) return rc;
     } else if (p.drop_thresh) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(nw * 64), 0, s, p);
@@ -2020,5 +2059,6 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
         hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(nw * 64), 0, s, p);
     }
     SS_LAUNCH_CHECK("attention_bwd");
+    if (dqkv_colsum) return simseg_colsum_accum(dqkv, 1, dqkv_colsum, B * T, 3 * H * 64, 3 * H * 64, stream);
     return 0;
 }

@@ -187,12 +187,13 @@ def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0, skip_padded_rows=False):
+def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0, skip_padded_rows=False, colsum=None):
+    """dqkv; colsum (optional fp32 [3*H*64]) += column sums of dqkv, the q/k/v bias gradient (formed inside the kernel for T <= 256)."""
     B, T, W = qkv.shape
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    ws = torch.empty(raw("simseg_attention_bwd_workspace_bytes", B, T, heads) // 4, device=qkv.device, dtype=torch.float32)
     _push_variant("attention")
-    call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(delta), ptr(dqkv),
+    call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(ws), ptr(dqkv), ptr(colsum),
          dt(qkv), B, T, heads, float(scale), int(drop_seed), float(drop_p), int(skip_padded_rows), stream())
     return dqkv
 

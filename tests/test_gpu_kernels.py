@@ -635,6 +635,37 @@ def test_attention_bwd_one_kernel_vs_two_passes(ops, T):
             _close(one, x.grad, 2e-2, f"one-kernel attention bwd T={T}")
 
 
+@pytest.mark.parametrize("T", [25, 77, 197, 256, 300])
+def test_attention_bwd_qkv_bias_gradient(ops, T):
+    """colsum += column sums of dqkv (the q/k/v bias gradient): formed inside the one-kernel backward for T <= 256, by a column-sum pass
+    otherwise (T = 300, fp32); accumulates into the caller's buffer; with skip_padded_rows only the rows the kernel works on count."""
+    B, H = 5, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T + 21, scale=1.2, dtype=torch.bfloat16)
+    dout = _rand(B, T, H * 64, seed=T + 22, dtype=torch.bfloat16)
+    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+    cs = torch.full((3 * H * 64,), 2.0, device="cuda")
+    dqkv = ops.attention_bwd(qkv, out, dout, lse, H, None, colsum=cs)
+    _close(cs - 2.0, dqkv.float().sum((0, 1)), 2e-5, f"qkv bias gradient T={T}")
+    assert torch.equal(dqkv, ops.attention_bwd(qkv, out, dout, lse, H, None))                  # dqkv itself does not change
+    x32 = qkv.float()
+    o32, l32 = ops.attention_fwd(x32, H, None, save_lse=True)
+    cs32 = torch.zeros(3 * H * 64, device="cuda")
+    d32 = ops.attention_bwd(x32, o32, dout.float(), l32, H, None, colsum=cs32)
+    _close(cs32, d32.sum((0, 1)), 2e-5, f"qkv bias gradient fp32 T={T}")
+    if T <= 256:
+        mask = torch.zeros(B, T, dtype=torch.long)
+        for b, n in enumerate((T, max(1, T // 2), 1, 7, T - 1)):
+            mask[b, :min(n, T)] = 1
+        mask = mask.cuda()
+        dm = dout * mask[:, :, None].to(dout.dtype)
+        for skip in (False, True):
+            out, lse = ops.attention_fwd(qkv, H, mask, save_lse=True, drop_seed=3, drop_p=0.1, skip_padded_rows=skip)
+            cs = torch.zeros(3 * H * 64, device="cuda")
+            dqkv = ops.attention_bwd(qkv, out, dm, lse, H, mask, drop_seed=3, drop_p=0.1, skip_padded_rows=skip, colsum=cs)
+            want = torch.where(mask[:, :, None].bool(), dqkv.float(), torch.zeros((), device="cuda")).sum((0, 1))      # (untouched rows may hold anything)
+            _close(cs, want, 2e-5, f"qkv bias gradient, ragged mask, skip_padded_rows={skip} T={T}")
+
+
 def test_attention_masked_length_limit(ops):
     qkv = _rand(1, 1100, 3 * 64, seed=1, dtype=torch.bfloat16)
     mask = torch.ones(1, 1100, dtype=torch.long, device="cuda")
