@@ -1845,17 +1845,21 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * OP + (lane & 7) * 16);
                 if (wave * 32 + row < T) *reinterpret_cast<u32x4*>(dbase + (long)row * RS + sel * p.H * 64 + (lane & 7) * 8) = v;
             }
-            if (p.colsum_ws) {       // lane = one of the tile's 64 columns: the sum of its (rounded, as stored) valid rows
-                const int nrow = min(32, T - wave * 32);
-                float c0_ = 0.f, c1_ = 0.f, c2_ = 0.f, c3_ = 0.f;
-                const bf16_t* col = reinterpret_cast<const bf16_t*>(ob) + lane;
-                int r = 0;
-                for (; r + 4 <= nrow; r += 4) {
-                    c0_ += (float)col[(r + 0) * (OP / 2)]; c1_ += (float)col[(r + 1) * (OP / 2)];
-                    c2_ += (float)col[(r + 2) * (OP / 2)]; c3_ += (float)col[(r + 3) * (OP / 2)];
+            if (p.colsum_ws) {       // column sums of the tile's (rounded, as stored) valid rows: lane = 4 columns x every 4th row, 8-byte reads
+                const int nrow = min(32, T - wave * 32), cg = lane & 15, rg = lane >> 4;
+                float c[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = rg + 4 * i;
+                    union { uint2 u; bf16_t hh[4]; } v;
+                    v.u = *reinterpret_cast<const uint2*>(ob + row * OP + cg * 8);        // (unconditional: a branch per row serialises the eight reads)
+                    const float keepf = row < nrow ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[e] = __builtin_fmaf((float)v.hh[e], keepf, c[e]);
                 }
-                for (; r < nrow; ++r) c0_ += (float)col[r * (OP / 2)];
-                cpart[(wave * 3 + sel) * 64 + lane] = (c0_ + c1_) + (c2_ + c3_);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c[e] += __shfl_xor(c[e], 16, 64); c[e] += __shfl_xor(c[e], 32, 64); }
+                if (rg == 0) *reinterpret_cast<float4*>(cpart + (wave * 3 + sel) * 64 + cg * 4) = make_float4(c[0], c[1], c[2], c[3]);
             }
             __builtin_amdgcn_wave_barrier();
         };
@@ -1864,7 +1868,9 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         put(dv, 2, 1.f);
     }
     if (p.colsum_ws) {           // this head's 3 x 64 column sums over its sequence: waves in a fixed order, plain stores (folded over B by the caller)
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() also waits for the block's global stores to be acknowledged (vmcnt(0)) - 3.7 us per block here,
+        // which otherwise drain after the last wave has gone
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int i = tid; i < 192; i += nthr) {
             const float* cpart = reinterpret_cast<const float*>(ldsQ);
             float c = 0.f;

@@ -623,8 +623,13 @@ extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int
     if (rows <= 0) return 0;
     int chunks = (int)((rows + 255) / 256);
     if (chunks > 512) chunks = 512;
+    const int nbx = (int)((N + 255) / 256);
+    if ((long)chunks * nbx < 512) {      // few rows (the [B, 3*H*64] partials of the attention backward: 18 blocks, each thread a chain of 32 loads - 100 us):
+        const long by_rows = (rows + 7) / 8, by_grid = (512 + nbx - 1) / nbx;        // down to 8 rows per block until the grid fills the chip
+        chunks = (int)(by_rows < by_grid ? by_rows : by_grid);
+    }
     const int rpb = (int)((rows + chunks - 1) / chunks);
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((rows + rpb - 1) / rpb));
+    dim3 grid((unsigned)nbx, (unsigned)((rows + rpb - 1) / rpb));
     if (in_dtype == 0)
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, STREAM, (const float*)in, out, (long)rows, (int)N, (long)ld, rpb);
     else

@@ -127,6 +127,9 @@ def _dgrad(d, w_, **kw):
     return ops.gemm(d, w_, trans_b=True, **kw)
 
 
+_FUSED_QKV_BIAS = os.environ.get("SIMSEG_AMD_FUSED_QKV_BIAS", "1") != "0"      # (A/B runs: 0 = a column-sum pass over dqkv instead)
+
+
 def _zeros_like_bias(out, n, device):
     """The accumulation target of a fused bias gradient: the caller's zeroed buffer, or a fresh one."""
     return torch.zeros(n, device=device, dtype=F32) if out is None else out
@@ -318,7 +321,10 @@ class ViTBlockFn(Function):
         datt = _dgrad(dx1_16, pw_)
         dpw = _wgrad(dx1_16, att.view(-1, D), dpw_z) if need[7] else None
         dqb = _zeros_like_bias(dqb_z, 3 * D, qkv.device) if need[6] else None       # the qkv bias gradient rides on the attention backward
-        dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5, colsum=dqb).view(-1, 3 * D)
+        dqkv = ops.attention_bwd(qkv.view(B, T, 3 * D), att, datt.view(B, T, D), lse, ctx.heads, None, scale=64 ** -0.5,
+                                 colsum=dqb if _FUSED_QKV_BIAS else None).view(-1, 3 * D)
+        if dqb is not None and not _FUSED_QKV_BIAS:
+            ops.colsum_accum(dqkv, dqb)
         dln1 = _dgrad(dqkv, qw_)
         dqw = _wgrad(dqkv, ln1.view(-1, D), dqw_z) if need[5] else None
         dx, dx16 = _ln_bwd(adt, x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dln1, dres=dx1_32, dxsum=dsum)
@@ -490,9 +496,12 @@ class BertLayerFn(Function):
         # (packed: rows of padded tokens carry no gradient - their dout is zero, their keys are masked - so the sums over the dense rows
         # the kernel works on equal the sums over the packed rows)
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
-                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD, colsum=dbqkv).view(-1, 3 * D)
+                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD,
+                                 colsum=dbqkv if _FUSED_QKV_BIAS else None).view(-1, 3 * D)
         if packed:
             dqkv = ops.gather_rows(dqkv, idx)                        # [Nv, 3D]
+        if dbqkv is not None and not _FUSED_QKV_BIAS:
+            ops.colsum_accum(dqkv, dbqkv)
         dx = _dgrad(dqkv, wqkv, residual=ds1_32, out_dtype=F32)
         dwqkv = _wgrad(dqkv, xa, dwqkv_z) if (need[6] or need[8] or need[10]) else None
         dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]

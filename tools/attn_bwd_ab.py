@@ -37,6 +37,10 @@ def main():
         do = torch.randn_like(o)
         if mask is not None:
             do = do * mask[:, :, None].to(do.dtype)       # the caller contract of skip_padded_rows: no gradient arrives on padded rows
+        cs = torch.zeros(3 * H * 64, device="cuda")
+        timeit(lambda: ops.attention_bwd(qkv, o, do, lse, H, mask, **kw), iters=60)       # (clock ramp after the idle set-up phase: the first ~30 ms run slower)
+        us = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, H, mask, colsum=cs, **kw))
+        print(f"{name} B={B} T={T} one kernel + q/k/v bias gradient: {us:.1f} us", flush=True)
         res = {}
         for v in (0, 3):
             ops.set_attention_variant(v)
