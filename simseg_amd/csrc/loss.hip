@@ -233,12 +233,42 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __r
     const long hi = min(sizes[t], lo + chunk);
     const float decay = 1.0f - T.lr * T.wd;
     const float step_size = T.lr / bc1;
-    for (long i = lo + threadIdx.x; i < hi; i += 256) {
-        const float gi = T.g[i] * grad_scale;
-        float pi = T.p[i] * decay;
-        const float mi = b1 * T.m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * T.v[i] + (1.0f - b2) * gi * gi;
+    auto one = [&](float g_, float& pi, float& mi, float& vi) {
+        const float gi = g_ * grad_scale;
+        pi *= decay;
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
         pi -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    };
+    // 16 bytes per lane and streaming (non-temporal) accesses when the chunk allows it: every array is touched exactly once per step
+    // (30 bytes per parameter, 5.9 GB for ViT-B + BERT-base)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const bool vec = (((uintptr_t)(T.g + lo) | (uintptr_t)(T.p + lo) | (uintptr_t)(T.m + lo) | (uintptr_t)(T.v + lo)) % 16 == 0) &&
+                     (!T.p16 || (uintptr_t)(T.p16 + lo) % 8 == 0);
+    long i0 = lo;
+    if (vec) {
+        const long n4 = (hi - lo) / 4;
+        for (long q = threadIdx.x; q < n4; q += 256) {
+            const long i = lo + 4 * q;
+            const f4 g4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(T.g + i));
+            f4 p4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(T.p + i));
+            f4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(T.m + i));
+            f4 v4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(T.v + i));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float pe = p4[e], me = m4[e], ve = v4[e]; one(g4[e], pe, me, ve); p4[e] = pe; m4[e] = me; v4[e] = ve; }
+            __builtin_nontemporal_store(p4, reinterpret_cast<f4*>(T.p + i));
+            __builtin_nontemporal_store(m4, reinterpret_cast<f4*>(T.m + i));
+            __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(T.v + i));
+            if (T.p16) {
+                bf16x4 o = {(bf16_t)p4[0], (bf16_t)p4[1], (bf16_t)p4[2], (bf16_t)p4[3]};
+                *reinterpret_cast<bf16x4*>(T.p16 + i) = o;             // (read by the next step's GEMMs: default policy)
+            }
+        }
+        i0 = lo + 4 * n4;
+    }
+    for (long i = i0 + threadIdx.x; i < hi; i += 256) {
+        float pi = T.p[i], mi = T.m[i], vi = T.v[i];
+        one(T.g[i], pi, mi, vi);
         T.p[i] = pi; T.m[i] = mi; T.v[i] = vi;
         if (T.p16) T.p16[i] = (bf16_t)pi;
     }

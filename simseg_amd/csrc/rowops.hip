@@ -25,6 +25,18 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
+// streaming variants: data that is read once / not re-read before it has left every cache anyway (the fp32 residual stream: 310 MB per
+// tensor at the training shape, more than the 256 MB memory-side cache)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load4_nt(const float* p, float (&v)[4]) {
+    const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void store4_nt(float* p, const float (&v)[4]) {
+    const f32x4_nt t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row.  x fp32 (residual stream) -> y (TO) [+ optional bf16 copy y2]
 // timm Block.norm1/norm2/norm (eps 1e-6), HF BertSelfOutput/BertOutput/BertEmbeddings LayerNorm (eps 1e-12)
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
-            load4<float>(xr + c * 4, v[i]);
+            load4_nt(xr + c * 4, v[i]);
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4];
                 if (dy16) load4<bf16_t>(dy16 + o, a);
                 if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
-                load4<float>(x + o, xv);
-                if (dres) load4<float>(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
+                load4_nt(x + o, xv);
+                if (dres) load4_nt(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float out[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + rr[i][j];
-                if (dx32) store4<float>(dx32 + o, out);
+                if (dx32) store4_nt(dx32 + o, out);
                 if (drop_thresh) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) out[j] = dropout_keep(drop_seed, (unsigned long long)o + j, drop_thresh) ? out[j] * drop_scale : 0.f;
