@@ -1139,8 +1139,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const long ro = (long)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h2) * p.ldr;
-                    xl[e] = p.residual[ro + c0 + cl];
-                    xr[e] = p.residual[ro + c1 + cl];
+                    xl[e] = __builtin_nontemporal_load(p.residual + ro + c0 + cl);       // the residual stream is read exactly once here
+                    xr[e] = __builtin_nontemporal_load(p.residual + ro + c1 + cl);
                 }
             };
             if (p.residual) load_res(0, rl[0], rr[0]);
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                         vr = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c1 + cl, p.drop_thresh) ? vr * p.drop_scale : 0.f;
                     }
                     if (p.residual) { vl += rl[i & 1][e]; vr += rr[i & 1][e]; }
-                    Cf[(long)row * p.ldc + c0 + cl] = vl;
+                    Cf[(long)row * p.ldc + c0 + cl] = vl;                         // (a non-temporal store here measured no different)
                     Cf[(long)row * p.ldc + c1 + cl] = vr;
                 }
             }
