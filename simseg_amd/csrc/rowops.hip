@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (c < nch) {
                 const long o = (long)row * D + c * 4;
                 float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4];
-                if (dy16) load4<bf16_t>(dy16 + o, a);
+                if (dy16) {
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dy16 + o));
+                    a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3];
+                }
                 if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
                 load4_nt(x + o, xv);
                 if (dres) load4_nt(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
