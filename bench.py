@@ -362,35 +362,72 @@ class ClockSampler:
     power-capped under matrix-core load: the dense peaks of MI355X_MICROARCH.md assume 2.4 GHz, the step runs at ~1.9 GHz / ~1.36 kW,
     a long-K GEMM alone at ~1.7 GHz / 1.4 kW (profiles/r2_clock_power_under_load.txt)."""
 
-    def __init__(self, period=0.3):
+    def __init__(self, period=0.3, bdf=None):
         import threading
-        self.samples, self._stop, self.period = [], False, period
+        self.samples, self._stop, self.period, self.t_from, self.bdf = [], False, period, 0.0, bdf
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
-    def _run(self):
+    def _sysfs(self):
+        """(sclk MHz, package W) straight from the amdgpu sysfs files rocm-smi reads - no fork / exec of a Python tool from a process
+        that has tens of GB mapped while the timed steps are being launched.  The card is the one whose PCI address is this process's
+        HIP device (a node shows all eight under /sys); None when that is unknown or the files are not there."""
+        import glob
+        import re
+        if not self.bdf:
+            return None
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if not os.path.realpath(dev).lower().endswith(self.bdf):
+                    continue
+                with open(dev + "/pp_dpm_sclk") as f:
+                    cur = [ln for ln in f.read().splitlines() if ln.strip().endswith("*")]
+                mhz = int(re.search(r"(\d+)\s*[Mm][Hh]z", cur[0]).group(1))
+                for name in ("power1_average", "power1_input"):
+                    hw = glob.glob(dev + "/hwmon/hwmon*/" + name)
+                    if hw:
+                        with open(hw[0]) as f:
+                            return mhz, int(f.read().strip()) / 1e6
+            except Exception:       # noqa: BLE001
+                continue
+        return None
+
+    @staticmethod
+    def _smi():
         import re
         import subprocess
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+        w = re.search(r"Power \(W\): ([0-9.]+)", out)
+        return (int(m.group(1)), float(w.group(1))) if m and w else None
+
+    def _run(self):
+        read = self._sysfs if self._sysfs() is not None else self._smi
+        self.source = "amdgpu sysfs" if read == self._sysfs else "rocm-smi"
         while not self._stop:
             try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
-                m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
-                w = re.search(r"Power \(W\): ([0-9.]+)", out)
-                if m and w:
-                    self.samples.append((int(m.group(1)), float(w.group(1))))
-            except Exception:       # noqa: BLE001  (no rocm-smi: the fields stay null)
+                v = read()
+                if v:
+                    self.samples.append((time.perf_counter(), v[0], v[1]))
+            except Exception:       # noqa: BLE001  (no rocm-smi either: the fields stay null)
                 return
             time.sleep(self.period)
+
+    def mark(self):
+        """Samples from here on count (the sampler is started BEFORE the warm-up steps, so that its own start-up - a cold rocm-smi on
+        a fresh box, if the sysfs files are missing - does not fall into the timed region)."""
+        self.t_from = time.perf_counter()
 
     def stop(self):
         self._stop = True
         self.th.join(timeout=15)
-        s = self.samples[1:] if len(self.samples) > 2 else self.samples       # (the first sample may predate the load)
+        s = [x[1:] for x in self.samples if x[0] >= self.t_from]
         if not s:
             return None
         sclk = sum(x[0] for x in s) / len(s)
         return {"sclk_mhz_avg": round(sclk, 0), "power_w_avg": round(sum(x[1] for x in s) / len(s), 0), "samples": len(s),
-                "nominal_sclk_mhz": 2400, "dense_bf16_peak_at_this_clock_tflops": round(PEAK_BF16 / 1e12 * sclk / 2400.0, 0)}
+                "nominal_sclk_mhz": 2400, "dense_bf16_peak_at_this_clock_tflops": round(PEAK_BF16 / 1e12 * sclk / 2400.0, 0),
+                "source": getattr(self, "source", None)}
 
 
 def main():
@@ -460,6 +497,13 @@ def main():
         opt.step()
         return loss_dict["nce_loss"]
 
+    bdf = None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:       # noqa: BLE001  (older torch: no PCI fields - rocm-smi then)
+        pass
+    clocks = ClockSampler(bdf=bdf) if rank == 0 else None      # clock / power from a side thread: the chip is power-capped under this load
     for i in range(args.warmup):
         step()
         if i == 0:
@@ -468,7 +512,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    clocks = ClockSampler() if rank == 0 else None      # rocm-smi from a side thread: the chip is power-capped under this load
+    if clocks is not None:
+        clocks.mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
