@@ -33,6 +33,20 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+TRAFFIC_JSON = "r3_pmc_traffic.json"
+
+
+def git_blob_sha1(path):
+    """git's blob id of a file (sha1 of "blob <size>\\0" + content) without git: the GPU box gets a snapshot with no .git, and the
+    PMC traffic entry must be tied to the kernel source it was measured on (`git rev-parse HEAD:simseg_amd/csrc/gemm.hip`)."""
+    import hashlib
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def flops_per_pair(n_patches, dim, seq, proj=512):
     """Algorithmic FLOPs of one image-text pair, fwd+bwd = 3x fwd."""
     t = n_patches + 1
@@ -321,6 +335,37 @@ def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
             "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
 
 
+def retrieval_multi_rank_bench(dev, rank, world, n_img=5000, cap=5, d=512, reps=3):
+    """The retrieval evaluation as N ranks run it (tools/retrieval_evaluation.py:65-99): every rank holds the embeddings of its shard
+    of the 25000 (image, caption) rows, the shards are all-gathered (equal counts: short shards padded with image_id = -1, dropped
+    after the gather), rank 0 computes both recall directions.  Timed: gather + metric (the encoders are timed by encoder_inclusive)."""
+    from simseg_amd.retrieval import evaluate_sharded
+    g = torch.Generator().manual_seed(5)
+    img = torch.nn.functional.normalize(torch.randn(n_img, d, generator=g), dim=-1)
+    rows = n_img * cap
+    txt = torch.nn.functional.normalize(img.repeat_interleave(cap, 0) + 0.08 * torch.randn(rows, d, generator=g), dim=-1)
+    per = (rows + world - 1) // world + (7 if rank == 0 else 0)          # uneven on purpose: the padding path runs
+    lo = min(rows, rank * ((rows + world - 1) // world) + (0 if rank == 0 else 7))
+    hi = min(rows, lo + per)
+    if rank == world - 1:
+        hi = rows
+    shard = {"image_embeddings": img.repeat_interleave(cap, 0)[lo:hi].contiguous().to(dev), "text_embeddings": txt[lo:hi].contiguous().to(dev),
+             "image_id": (torch.arange(rows) // cap)[lo:hi].to(dev), "caption_id": torch.arange(rows)[lo:hi].to(dev)}
+    out = evaluate_sharded(shard)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = evaluate_sharded(shard)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    if rank != 0:
+        return None
+    return {"ranks": world, "rows": rows, "ms_per_eval_incl_gather": round(dt * 1e3, 3), "I2T_R@1": round(out["coco_I2T-R@1"], 3),
+            "T2I_R@1": round(out["coco_T2I-R@1"], 3), "RSUM": round(out["coco_RSUM"], 3)}
+
+
 def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250):
     """Encoder-inclusive retrieval eval (README.md:185 / tools/retrieval_evaluation.py:60-100 at MSCOCO-5k shape): 5000 images at
     288^2 and 25000 captions of 25 tokens through the towers (bf16), then recalls in both directions.  Synthetic inputs,
@@ -439,6 +484,7 @@ def main():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--tag", default="vit_base_patch16_224_in21k")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seg", action="store_true", help="skip the zero-shot-seg eval stage measurement")
     args = ap.parse_args()
@@ -470,6 +516,22 @@ def main():
     dim = VIT_ARCH[args.tag]["dim"]
     cfg, build = build_model(args.tag, dim, args.img)
     init_device(cfg)                                   # RCCL process group (env://), ENV.rank/size/device
+    # what the process group itself reports (not the environment): backend, world size and the device every rank computes on
+    pg_info = {"backend": dist.get_backend() if dist.is_initialized() else None,
+               "world_size": dist.get_world_size() if dist.is_initialized() else 1}
+    me = {"rank": rank, "device": f"cuda:{local}", "name": torch.cuda.get_device_name(dev)}
+    try:
+        pr0 = torch.cuda.get_device_properties(dev)
+        me["pci"] = f"{pr0.pci_domain_id:04x}:{pr0.pci_bus_id:02x}:{pr0.pci_device_id:02x}.0"
+    except Exception:       # noqa: BLE001
+        pass
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        pg_info["ranks"] = ranks
+        assert len({r.get("pci", r["device"]) for r in ranks}) == world, f"two ranks share a device: {ranks}"
+    else:
+        pg_info["ranks"] = [me]
     from simseg.models import PIPELINE
     torch.manual_seed(1234)
     model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
@@ -485,12 +547,22 @@ def main():
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
     opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
     B, L = args.pairs_per_gpu, args.seq_len
-    batch = synthetic_batch(B, args.img, L, 30522, 1000 + rank, dev)
-    log("model and batch on device")
+    # NB pre-generated device batches, visited round-robin; the caption tensors handed to the model are FRESH tensor objects every
+    # step (a clone, as a loader delivers them), so whatever the model derives from a mask - towers.ragged_maps with its host read of
+    # the real-token count, clip_k_to_shortest - is rebuilt inside the timed region every step instead of being cached on the tensor
+    NB = max(1, args.batches)
+    batches = [synthetic_batch(B, args.img, L, 30522, 1000 + rank + 100 * i, dev) for i in range(NB)]
+    step_no = [0]
+    log(f"model and {NB} batches on device")
+
+    def next_batch():
+        b = batches[step_no[0] % NB]
+        step_no[0] += 1
+        return {"image": b["image"], "input_ids": b["input_ids"].clone(), "attention_mask": b["attention_mask"].clone()}
 
     def step():
         opt.zero_grad(set_to_none=(world == 1 or sync is not None))     # under DDP the grads are views into the all-reduce buckets
-        loss_dict, _, _ = net(batch)
+        loss_dict, _, _ = net(next_batch())
         loss_dict["nce_loss"].backward()
         if sync is not None:
             sync()
@@ -558,6 +630,7 @@ def main():
         two_streams = os.environ.get("SIMSEG_AMD_TWO_STREAMS") != "0"
     os.environ["SIMSEG_AMD_TWO_STREAMS"] = "0"
     ops.PROFILE = []
+    prof_lens = batches[step_no[0] % NB]["attention_mask"].sum(1).cpu()      # caption lengths of the instrumented step's batch
     step()
     torch.cuda.synchronize()
     if env_ts is None:
@@ -569,7 +642,7 @@ def main():
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
     ops.PROFILE = None
-    del net, model, opt, batch
+    del net, model, opt, batches
     torch.cuda.empty_cache()
     seg = None
     if not args.no_seg:
@@ -588,7 +661,10 @@ def main():
         if cpu_seg is not None:
             seg["cpu_baseline"] = cpu_seg
         log(f"seg eval stage: {seg}")
+    retr_multi = retrieval_multi_rank_bench(dev, rank, world) if (world > 1 and not args.no_seg) else None       # collective: every rank
     retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
+    if retr is not None and retr_multi is not None:
+        retr["multi_rank"] = retr_multi
     if retr is not None:
         retr["encoder_inclusive"] = retrieval_encode_bench(dev)
         if cpu_retr is not None:
@@ -602,17 +678,29 @@ def main():
         pairs = world * B * args.steps
         value = pairs / elapsed
         dom = max(agg, key=lambda k: agg[k][2])
+        packed = os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0" and os.environ.get("SIMSEG_AMD_SKIP_PAD_ROWS", "1") != "0"
+        t_img = n_patches + 1
+        attn_img = B * 12 * (dim // 64) * 4.0 * t_img * t_img * 64
+        attn_txt = 12 * 12 * 4.0 * 64 * (float((prof_lens.double() ** 2).sum()) if packed else B * float(L) * L)
+        exec_fl = sum(a[1] for a in agg.values()) + 3.0 * (attn_img + attn_txt)
         cnt, fl, sec = agg[dom]
         achieved = fl / sec / 1e12
         gemm_sec = sum(a[2] for a in agg.values())
         # HBM bytes per launch of that kernel: from the rocprofv3 PMC passes of THIS command on THIS round's kernels (counters cannot be
         # read from inside the process); the entry is used only if it was measured on the kernel variant that dominates now
         traffic, traffic_src = None, None
+        blob = git_blob_sha1(os.path.join(REPO, "simseg_amd", "csrc", "gemm.hip"))
         try:
-            with open(os.path.join(REPO, "profiles", "r2_pmc_traffic.json")) as f:
-                ent = json.load(f)["per_kind"].get(dom)
-            if ent:
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], f"profiles/r2_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of {ent['kernel'][:60]}"
+            with open(os.path.join(REPO, "profiles", TRAFFIC_JSON)) as f:
+                tj = json.load(f)
+            ent = tj["per_kind"].get(dom)
+            if ent and tj.get("gemm_hip_blob") == blob:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/{TRAFFIC_JSON} (PMC passes taken at commit {tj.get('commit')}, gemm.hip blob {blob[:12]} = this tree's): "
+                               f"FETCH_SIZE x2 + WRITE_SIZE of {ent['kernel'][:60]}")
+            elif ent:
+                traffic_src = (f"null: profiles/{TRAFFIC_JSON} was measured on gemm.hip blob {str(tj.get('gemm_hip_blob'))[:12]}, this tree has {blob[:12]} "
+                               "(re-run tools/profile_round.sh + tools/pmc_traffic_json.py)")
         except (OSError, ValueError, KeyError):
             pass
         kdesc = {"_P": "gemm_pp_kernel (256x256 tile, two wave groups in ping-pong, direct-to-LDS half-tile ring)",
@@ -626,6 +714,7 @@ def main():
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
+                       "process_group": pg_info, "batches_rotated": NB,
                        "gradient_sync": ("none" if world == 1 else (f"simseg_amd.parallel.GradSync ({dp})" if sync is not None else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",
@@ -642,8 +731,15 @@ def main():
                          "frac_of_peak_at_measured_clock": (round(achieved / clock_info["dense_bf16_peak_at_this_clock_tflops"], 4)
                                                             if clock_info else None)},
             "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),
-                           "whole_step_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
-                           "whole_step_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
+                           "algorithmic_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
+                           "algorithmic_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
+                           # EXECUTED work: every GEMM launch of the instrumented step (2 M N K as launched, incl. the zero rows that pad
+                           # the packed caption rows to full tiles) + the attention kernels' 4 T^2 64 per head forward and 2x that
+                           # backward, captions counted up to their own length when the padded rows are skipped
+                           "executed_tflop_per_rank_step": round(exec_fl / 1e12, 2),
+                           "whole_step_tflops_per_gpu": round(exec_fl / (elapsed / args.steps) / 1e12, 2),
+                           "whole_step_frac_of_bf16_peak": round(exec_fl / (elapsed / args.steps) / PEAK_BF16, 4),
+                           "whole_step_frac_counts": "executed FLOPs (the algorithmic_* keys count the reference's padded caption tokens too)",
                            "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4),

@@ -14,12 +14,16 @@ import torch
 from simseg.utils import logger
 from simseg.utils.interpolate_pe import interpolate_pos_embed
 
+_KNOWN_UNEXPECTED = ("position_ids",)       # a buffer of transformers 4.21.3 checkpoints, not a parameter here
 _HEAD_PREFIXES = ("head.", "head_dist.", "pre_logits.", "fc_norm.", "cls.", "pooler.", "bert.pooler.")
 
 
 def _adapt(sd, module):
     sd = {k: v for k, v in sd.items() if not k.startswith(_HEAD_PREFIXES)}
     sd = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in sd.items()}       # BertForPreTraining-style prefixes
+    # the original bert-base-uncased checkpoints name LayerNorm's parameters gamma / beta; HF's from_pretrained renames them on load
+    sd = {(k[:-len(".gamma")] + ".weight" if k.endswith(".gamma") else k[:-len(".beta")] + ".bias" if k.endswith(".beta") else k): v
+          for k, v in sd.items()}
     pe = sd.get("pos_embed")
     if pe is not None and hasattr(module, "pos_embed") and hasattr(module, "patch_embed") and pe.shape != module.pos_embed.shape:
         sd["pos_embed"] = interpolate_pos_embed(pe.float(), module)
@@ -32,7 +36,14 @@ def maybe_load_pretrained(module, tag):
     if path and os.path.exists(path):
         sd = _adapt(torch.load(path, map_location="cpu"), module)
         missing, unexpected = module.load_state_dict(sd, strict=False)
-        logger.info(f"loaded pretrained {tag} from {path} (missing {len(missing)}, unexpected {len(unexpected)})")
+        unexpected = [k for k in unexpected if not k.endswith(_KNOWN_UNEXPECTED)]
+        if missing:
+            # a file that only partly matches would leave those tensors at their random / identity init while reporting "pretrained"
+            raise KeyError(f"pretrained weights for {tag!r} ({path}) do not cover {len(missing)} tensors of the tower, e.g. "
+                           f"{sorted(missing)[:8]}; keys the file has that the tower does not: {sorted(unexpected)[:8]}")
+        if unexpected:
+            logger.warning(f"pretrained {tag}: {len(unexpected)} keys of {path} are not used: {sorted(unexpected)[:8]}")
+        logger.info(f"loaded pretrained {tag} from {path} (every tensor of the tower covered)")
         return True
     if os.environ.get("SIMSEG_ALLOW_RANDOM_INIT", "0") not in ("", "0"):
         logger.warning(f"pretrained weights for {tag} are not available offline; keeping the random init (SIMSEG_ALLOW_RANDOM_INIT)")

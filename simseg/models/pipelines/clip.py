@@ -12,8 +12,8 @@ import torch.nn as nn
 from simseg.models.backbones.builder import BACKBONE
 from simseg.models.criteria.losses.builder import LOSS
 from simseg.models.pipelines.builder import PIPELINE
-from simseg.utils import ENV
-from simseg_amd.heads import prefetch_gather
+from simseg.utils import ENV, logger
+from simseg_amd.heads import discard_prefetched, prefetch_gather
 from simseg_amd.nn import compute_dtype
 from simseg_amd.towers import ProjectPoolFn, packed_text
 
@@ -103,6 +103,7 @@ class CLIPModel(nn.Module):
         if embeddings == "text":
             return self.forward_text_feature(batch["input_ids"], batch["attention_mask"])
         image, ids, mask = batch["image"], batch["input_ids"], batch["attention_mask"]
+        discard_prefetched(logger.warning)           # gathers of an earlier step that never reached the loss
         if image.is_cuda and _two_streams_ok():
             # The two towers are independent until the loss: the text tower runs on a second HIP stream so that its kernels
             # fill the CUs the image tower's kernels leave idle (partial last rounds of the 256-CU tile grids, memory-bound

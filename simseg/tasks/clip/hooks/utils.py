@@ -5,7 +5,7 @@ from typing import Any, Dict
 
 import torch
 
-from simseg_amd.heads import retrieval_recalls
+from simseg_amd.heads import retrieval_recalls_both
 
 __all__ = ["IndexedEmbInfo", "EmbANN", "RetrievalMetric"]
 
@@ -37,9 +37,26 @@ class RetrievalMetric:
     def __init__(self, with_prefix=True):
         self.recall_range = (1, 5, 10)
         self.with_prefix = with_prefix
+        self._reverse = None       # (key of the swapped call, its tensors kept alive, its result)
+
+    @staticmethod
+    def _key(*tensors):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
 
     def __call__(self, leftemb: IndexedEmbInfo, rightemb: IndexedEmbInfo) -> Dict[str, Any]:
-        res = retrieval_recalls(leftemb.emb_mat, leftemb.group_idx, rightemb.emb_mat, rightemb.group_idx, self.recall_range)
+        # The evaluation calls the metric twice with swapped arguments (tools/retrieval_evaluation.py:44-45).  Both directions come from ONE
+        # similarity matrix (rows rank their columns, columns rank their rows - heads.retrieval_recalls_both), so the first call also
+        # produces the swapped call's answer and keeps it, keyed on the identity and version of the four tensors; the second call then
+        # launches nothing.  An entry is used once; tensors modified in place or replaced in between miss the key and are recomputed.
+        tensors = (leftemb.emb_mat, leftemb.group_idx, rightemb.emb_mat, rightemb.group_idx)
+        key = self._key(*tensors)
+        memo, self._reverse = self._reverse, None
+        if memo is not None and memo[0] == key and all(a is b for a, b in zip(memo[1], tensors)):
+            res = memo[2]
+        else:
+            res, rev = retrieval_recalls_both(*tensors, self.recall_range)
+            swapped = (rightemb.emb_mat, rightemb.group_idx, leftemb.emb_mat, leftemb.group_idx)
+            self._reverse = (self._key(*swapped), swapped, rev)
         if self.with_prefix:
             prefix = f"[{leftemb.emb_name}] to [{rightemb.emb_name}]:"
             res = {f"{prefix} {k}": v for k, v in res.items()}

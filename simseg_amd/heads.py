@@ -34,6 +34,26 @@ def prefetch_gather(tensor, group=None):
     _PREFETCH[id(tensor)] = (weakref.ref(tensor), t, out, work, group)
 
 
+def discard_prefetched(log=None):
+    """Drop every prefetched gather nobody picked up (the loss was not reached - an exception, or a custom loss that normalises / casts
+    the embeddings before gathering them): the collective is waited for so that its buffers can be recycled, and the entry is removed.
+    CLIPModel.forward calls this first, so a missed hand-over costs one redundant collective once instead of leaking a buffer and a Work
+    handle every step.  Returns the number of discarded entries."""
+    n = 0
+    for key in list(_PREFETCH):
+        ent = _PREFETCH.pop(key, None)
+        if ent is None:
+            continue
+        try:
+            ent[3].wait()
+        except Exception:       # noqa: BLE001  (a failed collective of an abandoned step)
+            pass
+        n += 1
+    if n and log is not None:
+        log(f"simseg_amd.heads: {n} prefetched embedding gather(s) were never consumed and have been discarded")
+    return n
+
+
 def _take_prefetched(tensor, group):
     ent = _PREFETCH.pop(id(tensor), None)
     if ent is None or ent[0]() is not tensor or ent[4] is not group:

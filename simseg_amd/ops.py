@@ -173,24 +173,31 @@ def topk_pool_l2norm_bwd(demb, emb, norm, idx, N, dtype, eps=1e-8, normalize=Tru
     return dtok
 
 
-def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0, skip_padded_rows=False):
-    """qkv [B,T,3*H*64] packed (3,H,64) -> ctx [B,T,H*64]."""
+def attention_fwd(qkv, heads, mask=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0, skip_padded_rows=False, zero_skipped=True):
+    """qkv [B,T,3*H*64] packed (3,H,64) -> ctx [B,T,H*64].
+    skip_padded_rows: the kernels do not write the rows past a sequence's last unmasked key (include/simseg_hip.h).  Those rows of the
+    returned tensors are zeros unless the caller passes zero_skipped=False because it provably never reads them (the packed text
+    tower gathers the real rows only and saves a fill pass per layer)."""
     require_gpu(qkv)
     B, T, W = qkv.shape
     if W != 3 * heads * 64:
         raise ValueError("attention: qkv last dim must be 3*heads*64")
-    out = torch.empty(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
-    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
+    alloc = torch.zeros if (skip_padded_rows and zero_skipped) else torch.empty
+    out = alloc(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = alloc(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
     _push_variant("attention")
     call("simseg_attention_fwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(out), ptr(lse), dt(qkv), B, T, heads, float(scale),
          int(drop_seed), float(drop_p), int(skip_padded_rows), stream())
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0, skip_padded_rows=False, colsum=None):
-    """dqkv; colsum (optional fp32 [3*H*64]) += column sums of dqkv, the q/k/v bias gradient (formed inside the kernel for T <= 256)."""
+def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=0, drop_p=0.0, skip_padded_rows=False, colsum=None,
+                  zero_skipped=True):
+    """dqkv; colsum (optional fp32 [3*H*64]) += column sums of dqkv, the q/k/v bias gradient (formed inside the kernel for T <= 256).
+    skip_padded_rows / zero_skipped: as in attention_fwd - the skipped rows of dqkv are zeros (their true gradient) unless the caller
+    never reads them."""
     B, T, W = qkv.shape
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.zeros_like(qkv) if (skip_padded_rows and zero_skipped) else torch.empty_like(qkv)
     ws = torch.empty(raw("simseg_attention_bwd_workspace_bytes", B, T, heads) // 4, device=qkv.device, dtype=torch.float32)
     _push_variant("attention")
     call("simseg_attention_bwd", ptr(_c(qkv)), ptr(_c(mask)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(ws), ptr(dqkv), ptr(colsum),

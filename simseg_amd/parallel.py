@@ -79,10 +79,15 @@ class GradSync:
     def _make_hook(self, i):
         def hook(p):
             v = self.views[i]
+            b = self._bucket_of[i]
+            if self._pending[b] <= 0:
+                # this bucket's all-reduce is already enqueued: a second backward before finish() (gradient accumulation) would add
+                # into the flat views while that collective may still be in flight - partly reduced gradients and a data race
+                raise RuntimeError("GradSync(overlap=True): a parameter's gradient arrived again after its bucket was reduced - exactly one "
+                                   "backward per finish(); for gradient accumulation use GradSync(overlap=False) or accumulate inside one backward")
             if p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-            b = self._bucket_of[i]
             if self.flat.is_cuda:
                 ev = torch.cuda.Event()
                 ev.record()                       # on the stream this gradient was produced on (main or the text tower's)

@@ -449,7 +449,7 @@ class BertLayerFn(Function):
         if packed:
             qkv = ops.gather_rows(qkv, inv)                          # [B*L, 3D], zero rows at the padded positions
         att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p,
-                                      skip_padded_rows=packed and _SKIP_PAD)
+                                      skip_padded_rows=packed and _SKIP_PAD, zero_skipped=False)      # (only real rows are gathered below)
         attd = att
         if packed:
             att = ops.gather_rows(att.view(-1, D), idx)              # [Nv, D]
@@ -497,7 +497,7 @@ class BertLayerFn(Function):
         # the kernel works on equal the sums over the packed rows)
         dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
                                  scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD,
-                                 colsum=dbqkv if _FUSED_QKV_BIAS else None).view(-1, 3 * D)
+                                 colsum=dbqkv if _FUSED_QKV_BIAS else None, zero_skipped=False).view(-1, 3 * D)
         if packed:
             dqkv = ops.gather_rows(dqkv, idx)                        # [Nv, 3D]
         if dbqkv is not None and not _FUSED_QKV_BIAS:

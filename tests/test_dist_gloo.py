@@ -84,6 +84,25 @@ def _worker(rank, world, port, q):
             lin2(x).square().sum().backward()
             s2.finish()
         res.setdefault("gsync_alt", []).append([p.grad.tolist() for p in lin2.parameters()])
+    # a second backward before finish(): the overlapped exchange refuses it (its buckets are already reduced) instead of racing
+    s3 = GradSync(lin.parameters(), overlap=True)
+    lin(x).square().sum().backward()
+    try:
+        lin(x).square().sum().backward()
+        res["gsync_double"] = "no error"
+    except RuntimeError as e:
+        res["gsync_double"] = str(e)
+    for h in s3._handles:
+        h.remove()
+    # multi-rank retrieval evaluation: uneven shards padded with image_id = -1, gathered, padding dropped (retrieval_evaluation.py:89-95)
+    from simseg_amd.retrieval import gather_retrieval_sets
+    gen = torch.Generator().manual_seed(5)
+    n_all, P = 12, 8
+    full = {"image_embeddings": torch.randn(n_all, P, generator=gen), "text_embeddings": torch.randn(n_all, P, generator=gen),
+            "image_id": torch.arange(n_all) // 3, "caption_id": torch.arange(n_all)}
+    lo, hi = (0, 7) if rank == 0 else (7, 12)                    # 7 and 5 rows
+    got = gather_retrieval_sets({k: v[lo:hi] for k, v in full.items()})
+    res["retr_gather"] = all(torch.equal(got[k], full[k]) for k in full)
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -114,6 +133,8 @@ def test_gather_layer_matches_reference_two_ranks(world):
         assert o["blist"] == [1, 8]
         assert o["bobj"] == [{"rank": 0}, "x"]
         assert o["gsync"][2]
+        assert "exactly one backward per finish()" in o["gsync_double"], o["gsync_double"]
+        assert o["retr_gather"]
     for r in range(world):                                       # flat / multi-bucket variants agree with the default
         for alt in out[r]["gsync_alt"]:
             ref = [g_ for g_ in out[r]["gsync"][1]]

@@ -121,3 +121,108 @@ def test_two_ranks_match_reference_two_process_run(world):
                                                                 # (an exchange bug is O(1): the exact-fp32 loss part above is the tight check)
                     bad.append((r, two, name, c, ratio))
             assert not bad, bad
+
+
+def _worker_sync_and_retrieval(rank, world, port, backend, q):
+    """(a) GradSync(overlap=True) with the towers on two streams == torch DDP's averaged gradients; (b) the multi-rank retrieval
+    evaluation == the single-process one."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if torch.cuda.device_count() >= world else 0), SIMSEG_AMD_COMPUTE="fp32")
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from simseg.utils import ENV
+        ENV.rank, ENV.size, ENV.local_rank = rank, world, dev.index
+        from simseg_amd.parallel import GradSync
+        from test_gpu_model import _build
+        g = np.load(os.path.join(GOLD, f"clip_train_ws{world}.npz"))
+
+        def golden(name):
+            return np.load(os.path.join(GOLD, name + ".npz"))
+
+        batch = {k: torch.from_numpy(g[f"r{rank}.{k}"]).to(dev) for k in ("image", "input_ids", "attention_mask")}
+        res = {}
+        # torch DDP (towers on one stream under it: simseg/models/pipelines/clip.py:_two_streams_ok)
+        os.environ.pop("SIMSEG_AMD_TWO_STREAMS", None)
+        m1 = _build(golden).eval()                      # eval(): BERT dropout off, so both runs see the same function
+        ddp = torch.nn.parallel.DistributedDataParallel(m1, device_ids=[dev.index], gradient_as_bucket_view=True)
+        ddp(batch)[0]["nce_loss"].backward()
+        torch.cuda.synchronize()
+        want = {n: p.grad.detach().float().cpu().numpy() for n, p in m1.named_parameters() if p.grad is not None}
+        del ddp
+        # this package's exchange, hooks + communication stream, several small buckets, the text tower on its own stream
+        os.environ["SIMSEG_AMD_TWO_STREAMS"] = "1"
+        m2 = _build(golden).eval()
+        sync = GradSync(m2.parameters(), overlap=True, bucket_mb=0)        # bucket_mb=0: one bucket per parameter - the most hooks / events
+        for _ in range(2):                                                    # second step: the hooks re-arm after finish()
+            for p in m2.parameters():
+                p.grad = None
+            m2(batch)[0]["nce_loss"].backward()
+            sync.finish()
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().float().cpu().numpy() for n, p in m2.named_parameters() if p.grad is not None}
+        res["grads"] = (want, got, len(sync.buckets))
+        # one large bucket set (the default 64 MiB) as well
+        m3 = _build(golden).eval()
+        sync3 = GradSync(m3.parameters(), overlap=True)
+        m3(batch)[0]["nce_loss"].backward()
+        sync3.finish()
+        torch.cuda.synchronize()
+        res["grads_default_buckets"] = {n: p.grad.detach().float().cpu().numpy() for n, p in m3.named_parameters() if p.grad is not None}
+        os.environ.pop("SIMSEG_AMD_TWO_STREAMS", None)
+
+        # (b) retrieval: 60 images x 5 captions, rows dealt to the ranks unevenly (rank 0: 170 rows, rank 1: 130)
+        from simseg_amd.retrieval import evaluate_sharded, retrieval_metrics
+        gen = torch.Generator().manual_seed(5)
+        n_img, cap, P = 60, 5, 64
+        base = torch.nn.functional.normalize(torch.randn(n_img, P, generator=gen), dim=-1)
+        rows = n_img * cap
+        full = {"image_embeddings": base.repeat_interleave(cap, 0),
+                "text_embeddings": torch.nn.functional.normalize(base.repeat_interleave(cap, 0) + 0.35 * torch.randn(rows, P, generator=gen), dim=-1),
+                "image_id": torch.arange(rows) // cap, "caption_id": torch.arange(rows)}
+        lo, hi = (0, 170) if rank == 0 else (170, rows)
+        shard = {k: v[lo:hi].to(dev) for k, v in full.items()}
+        res["retr_multi"] = evaluate_sharded(shard, "coco")
+        if rank == 0:
+            res["retr_single"] = retrieval_metrics({k: v.to(dev) for k, v in full.items()}, "coco")
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gradsync_overlap_equals_ddp_and_sharded_retrieval_equals_single(world):
+    """the RCCL-side paths that had only run on gloo/CPU - GradSync's hooks, events and communication stream with
+    the HIP towers on two streams against torch DDP's gradients, and the multi-rank retrieval evaluation (a14) against the
+    single-process recalls."""
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync_and_retrieval, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        want, got, nb = out[r]["grads"]
+        assert nb > 20 and set(want) == set(got)
+        for name in want:
+            scale = float(np.abs(want[name]).max()) + 1e-12
+            # exact-fp32 kernels on both sides; the differences are the order of the two ranks' sum and atomics inside kernels
+            np.testing.assert_allclose(got[name], want[name], rtol=0, atol=2e-5 * scale + 1e-9, err_msg=f"rank {r} {name}")
+            np.testing.assert_allclose(out[r]["grads_default_buckets"][name], want[name], rtol=0, atol=2e-5 * scale + 1e-9, err_msg=f"rank {r} {name} (64 MiB buckets)")
+    for name in out[0]["grads"][1]:              # averaged gradients are the same on every rank
+        np.testing.assert_array_equal(out[0]["grads"][1][name], out[1]["grads"][1][name])
+    assert out[1]["retr_multi"] is None
+    multi, single = out[0]["retr_multi"], out[0]["retr_single"]
+    assert multi == single, (multi, single)      # same dot products, same integer ranks: bit-equal
+    assert 0.0 < multi["coco_I2T-R@1"] < 100.0 and len(multi) == 7

@@ -551,6 +551,8 @@ def test_attention_skip_padded_rows(ops, T):
             n = n if n > 0 else T                # nothing unmasked: dense
             assert torch.equal(out_s[b, :n], out_d[b, :n]) and torch.equal(lse_s[b, :, :n], lse_d[b, :, :n]), (T, b, p)
             assert torch.equal(g_s[b, :n], g_d[b, :n]), (T, b, p)
+            # the public op's contract: rows the kernels skip come back as zeros (their true gradient), never as uninitialised memory
+            assert not out_s[b, n:].any() and not g_s[b, n:].any() and not lse_s[b, :, n:].any(), (T, b, p)
 
 
 @pytest.mark.parametrize("T", [77, 197, 600])

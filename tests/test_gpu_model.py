@@ -334,9 +334,32 @@ def test_retrieval_metric_mirror_vs_reference_golden(golden):
     assert torch.equal(img.group_idx.cpu(), tt(g["uni_gid"])) and torch.equal(img.emb_mat.cpu(), tt(g["uni_emb"]))
     txt = IndexedEmbInfo("text", tt(g["gid_txt"]).cuda(), tt(g["txt"]).cuda())
     m = RetrievalMetric()
-    i2t, t2i = m(img, txt), m(txt, img)
+    from simseg_amd import ops
+    ops.PROFILE = []                       # every simseg_gemm launch is recorded
+    try:
+        i2t = m(img, txt)
+        n_first = len(ops.PROFILE)
+        t2i = m(txt, img)                  # the swapped call of tools/retrieval_evaluation.py:44-45: answered from the first call's matrix
+        n_second = len(ops.PROFILE) - n_first
+        again = m(txt, img)                # a memo entry is used once: an unpaired call computes
+        n_third = len(ops.PROFILE) - n_first - n_second
+    finally:
+        ops.PROFILE = None
+    assert (n_first, n_second, n_third) == (1, 0, 1), (n_first, n_second, n_third)
+    assert again == t2i
     np.testing.assert_allclose([i2t[f"[image] to [text]: R@{k}"] for k in (1, 5, 10)], g["i2t"], atol=1e-7)
     np.testing.assert_allclose([t2i[f"[text] to [image]: R@{k}"] for k in (1, 5, 10)], g["t2i"], atol=1e-7)
+    # tensors changed in place between the two calls miss the memo (version counter) and are recomputed on the new values
+    m2 = RetrievalMetric()
+    m2(img, txt)
+    txt.emb_mat.mul_(1.0)
+    ops.PROFILE = []
+    try:
+        r = m2(txt, img)
+        assert len(ops.PROFILE) == 1
+    finally:
+        ops.PROFILE = None
+    assert r == t2i
 
 
 def test_seg_similarity_map_vs_reference_golden(golden, monkeypatch):

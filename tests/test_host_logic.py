@@ -241,3 +241,35 @@ def test_ragged_maps_for_the_packed_text_tower():
     full = torch.ones(2, 5, dtype=torch.long)
     idx3, _, nv3 = ragged_maps(full, multiple=8)
     assert nv3 == 10 and idx3.numel() == 10                          # nothing to drop: no padding beyond the dense size
+
+
+def test_integration_md_bindings_match_the_header():
+    """The reference-side ctypes stubs shown in INTEGRATION.md must bind the entry points as include/simseg_hip.h declares them:
+    every `argtypes` list equals the header's (type for type) and every `_lib.simseg_*` call passes that many arguments."""
+    import ast
+    import re
+    from simseg_amd import lib
+    decl = lib.parse_header()
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    assert blocks, "INTEGRATION.md shows no Python binding"
+    n_argtypes = n_calls = 0
+    for b in blocks:
+        tree = ast.parse(b)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) and node.targets[0].attr in ("argtypes", "restype"):
+                fn = node.targets[0].value
+                assert isinstance(fn, ast.Attribute) and fn.attr in decl, f"INTEGRATION.md binds unknown symbol {ast.unparse(fn)}"
+                val = eval(compile(ast.Expression(node.value), "INTEGRATION.md", "eval"), {"ctypes": ctypes})
+                ret, args = decl[fn.attr]
+                if node.targets[0].attr == "argtypes":
+                    assert list(val) == [a for a, _ in args], f"{fn.attr}: argtypes in INTEGRATION.md differ from the header ({len(val)} vs {len(args)} parameters)"
+                    n_argtypes += 1
+                else:
+                    assert val is ret, f"{fn.attr}: restype in INTEGRATION.md differs from the header"
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in decl \
+                    and isinstance(node.func.value, ast.Name) and node.func.value.id == "_lib":
+                assert len(node.args) == len(decl[node.func.attr][1]), \
+                    f"{node.func.attr}: INTEGRATION.md passes {len(node.args)} arguments, the header declares {len(decl[node.func.attr][1])}"
+                n_calls += 1
+    assert n_argtypes >= 2 and n_calls >= 3

@@ -39,7 +39,17 @@ def main(prefix="profiles/r1"):
         if k:
             res[k] = {"kernel": name, "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": w.get(name),
                       "hbm_bytes_per_launch": int((2 * fetch + (w.get(name) or 0)) * 1024)}
-    json.dump({"command": "SIMSEG_AMD_TWO_STREAMS=0 rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-seg",
+    import hashlib
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = open(os.path.join(repo, "simseg_amd", "csrc", "gemm.hip"), "rb").read()
+    blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()      # = git rev-parse HEAD:simseg_amd/csrc/gemm.hip when committed
+    try:
+        commit = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    json.dump({"commit": commit, "gemm_hip_blob": blob, "command": "SIMSEG_AMD_TWO_STREAMS=0 rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-seg",
                "note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
                        "wide coalesced read); WRITE_SIZE is uncalibrated there", "per_kind": res}, open(prefix + "_pmc_traffic.json", "w"), indent=1)
     for k, v in sorted(res.items()):
