@@ -494,7 +494,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("SIMSEG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", 0)))     # override: bring-up of N ranks on one GPU
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    from simseg.utils import ENV
+    from simseg.utils import ENV, logger
+    logger.STREAM = sys.stderr          # stdout carries the one JSON line only
     ENV.local_rank = local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

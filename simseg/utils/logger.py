@@ -7,6 +7,9 @@ _COLORS = {"I": "", "E": "\033[0;32m", "W": "\033[0;33m", "X": "\033[0;31m", "D"
 _RESET = "\033[0m"
 
 
+STREAM = None      # None = stdout (the reference's logger prints); bench.py points it at stderr so that stdout carries its one JSON line only
+
+
 def _emit(tag, args, root_only):
     from .context import ENV
     if root_only and ENV.rank != 0:
@@ -17,7 +20,7 @@ def _emit(tag, args, root_only):
     body = " ".join(str(a) for a in args)
     color = _COLORS[tag]
     print(f"{color}{'I' if tag == 'E' else tag if tag != 'X' else 'E'} {stamp} {where:<18} #{ENV.rank}] {body}{_RESET if color else ''}",
-          flush=True)
+          flush=True, file=STREAM or sys.stdout)
 
 
 def info(*args, root_only=True):

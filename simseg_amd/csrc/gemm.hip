@@ -826,6 +826,10 @@ struct PPFrag {
 #pragma unroll
         for (int i = 0; i < (TRANS ? NB : 4); ++i) asm volatile("" : "+v"(a[i]));      // keep them as they are: base + immediate reads
     }
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int i = 0; i < (TRANS ? NB : 4); ++i) asm volatile("" : "+v"(a[i]));
+    }
     __device__ __forceinline__ void toggle(unsigned bit) {
 #pragma unroll
         for (int i = 0; i < (TRANS ? NB : 4); ++i) a[i] ^= bit;
@@ -845,6 +849,170 @@ struct PPFrag {
         }
     }
 };
+
+// ---- accumulator-layout epilogues of the 256x256 ping-pong kernels (shared by the per-tile and the persistent kernel) -------------
+// bf16 output without a per-element loaded operand (qkv / fc1 forward, the plain dgrads - most of the step's GEMM launches):
+// bias / GELU run on the accumulators in MFMA layout (a lane owns ONE column: the bias is a scalar per lane), pairs of rows are packed to
+// bf16, staged TRANSPOSED ([column][row], 8-byte writes) in the wave's 4608-byte scratch `tl` and read back through ds_read_b64_tr_b16, which
+// hands every lane 4 consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per 32x64 block.
+__device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x16 (&acc)[4][2], char* tl, int m0, int c0, int c1, int grp, int lane) {
+    constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
+    const int cl = lane & 31, h2 = lane >> 5, g4 = lane >> 4, a16 = lane & 15;
+    const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+    bf16_t* Xb = reinterpret_cast<bf16_t*>(p.aux_out);
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+    auto emit = [&](const f32x16& xl, const f32x16& xr, bf16_t* dst, int row0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            union { bf16_t h[4]; uint2 u; } pl, pr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pl.h[e] = (bf16_t)xl[4 * q + e]; pr.h[e] = (bf16_t)xr[4 * q + e]; }
+            *reinterpret_cast<uint2*>(tl + cl * TP + (8 * q + 4 * h2) * 2) = pl.u;
+            *reinterpret_cast<uint2*>(tl + (32 + cl) * TP + (8 * q + 4 * h2) * 2) = pr.u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // this lane's four 8-column groups of its row: columns c0 + 8 (g4 >> 1) + {0, 16, 128, 144} (c1 = c0 + 128): one
+        // address, immediate offsets
+        bf16_t* drow = dst + (long)(row0 + (g4 & 1) * 16 + a16) * p.ldc + c0 + (g4 >> 1) * 8;
+        const char* src0 = tl + ((g4 >> 1) * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const char* src = src0 + sidx * 16 * TP;         // staged column octet (g4 >> 1) + 2 sidx: 0-3 left fragment, 4-7 right
+            union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
+            u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
+            u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 4 * TP));
+            *reinterpret_cast<u32x4*>(drow + (sidx & 1) * 16 + (sidx >> 1) * 128) = u.v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (p.act == 4) {
+        // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major
+        // like the output: it takes the reverse trip - 16-byte row-major loads, staged [row][column], and ds_read_b64_tr_b16
+        // hands lane (column c) the 4 consecutive rows of each accumulator register group.  The loads of block i + 1 are
+        // requested before the stores of block i.
+        constexpr int PA = 144;                              // bytes per staged row (64 columns x 2 B + 16 B pad)
+        const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux);
+        const int trow = (g4 & 1) * 16 + a16;
+        const bf16_t* arow = Ab + (long)(m0 + grp * 64 + trow) * p.ldc + c0 + (g4 >> 1) * 8;
+        u32x4 ax[2][4];
+        auto load_aux = [&](int i, u32x4 (&dst)[4]) {
+            const bf16_t* a_i = arow + (long)((i >> 1) * 128 + (i & 1) * 32) * p.ldc;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) dst[sidx] = *reinterpret_cast<const u32x4*>(a_i + (sidx & 1) * 16 + (sidx >> 1) * 128);
+        };
+        load_aux(0, ax[0]);
+        float sL = 0.f, sR = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) load_aux(i + 1, ax[(i + 1) & 1]);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+                *reinterpret_cast<u32x4*>(tl + trow * PA + ((g4 >> 1) + 2 * sidx) * 16) = ax[i & 1][sidx];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x16 l, r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* src = tl + (8 * q + 4 * h2 + (a16 >> 2)) * PA + (((cl >> 4) * 16) + (a16 & 3) * 4) * 2;
+                const s16x4 tL = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
+                const s16x4 tR = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 64));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float al = __uint_as_float((unsigned)(unsigned short)tL[e] << 16), ar = __uint_as_float((unsigned)(unsigned short)tR[e] << 16);
+                    l[4 * q + e] = (acc[i][0][4 * q + e] * p.alpha + bL) * al;
+                    r[4 * q + e] = (acc[i][1][4 * q + e] * p.alpha + bR) * ar;
+                    sL += l[4 * q + e]; sR += r[4 * q + e];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+        if (p.colsum) {
+            sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
+            if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
+        }
+    } else if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x16 l, r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { l[e] = acc[i][0][e] * p.alpha + bL; r[e] = acc[i][1][e] * p.alpha + bR; }
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+    } else if (p.act == 3 && Xb) {     // the training forward of fc1: GELU stored, GELU' saved - unrolled (static accumulator indices)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x16 l, r, dl, dr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float d0, d1;
+                l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
+                r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
+                dl[e] = d0; dr[e] = d1;
+            }
+            const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+            emit(l, r, Cb, row0);
+            emit(dl, dr, Xb, row0);
+        }
+    } else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // (static accumulator indices: a rolled loop over the by-reference array ends up indexing it in scratch memory)
+        f32x16 l = acc[i][0], r = acc[i][1];
+        const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+        f32x16 dl, dr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float vl = l[e] * p.alpha + bL, vr = r[e] * p.alpha + bR;
+            dl[e] = vl; dr[e] = vr;                          // act 1: the saved pre-activation
+            if (p.act == 1) { vl = gelu_poly(vl); vr = gelu_poly(vr); }
+            else if (p.act == 3) { float d0, d1; vl = gelu_poly_grad(vl, d0); vr = gelu_poly_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
+            l[e] = vl; r[e] = vr;
+        }
+        emit(l, r, Cb, row0);
+        if (p.act != 0 && Xb) emit(dl, dr, Xb, row0);
+    }
+}
+
+// fp32 output (proj / fc2 forward: bias + dropout + fp32 residual): in the MFMA layout a lane owns one column and a store instruction covers
+// 32 consecutive floats of a row per half-wave - whole 128-byte lines - so the accumulators are finished and stored where they are, the
+// residual is loaded the same way, and nothing goes through LDS.
+__device__ __forceinline__ void pp_epilogue_f32_direct(const GemmParams& p, const f32x16 (&acc)[4][2], int m0, int c0, int c1, int grp, int lane) {
+    const int cl = lane & 31, h2 = lane >> 5;
+    const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
+    float* Cf = reinterpret_cast<float*>(p.C);
+    f32x16 rl[2], rr[2];                                     // residual of the current / next fragment pair
+    auto load_res = [&](int i, f32x16& xl, f32x16& xr) {
+        const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long ro = (long)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h2) * p.ldr;
+            xl[e] = __builtin_nontemporal_load(p.residual + ro + c0 + cl);       // the residual stream is read exactly once here
+            xr[e] = __builtin_nontemporal_load(p.residual + ro + c1 + cl);
+        }
+    };
+    if (p.residual) load_res(0, rl[0], rr[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (p.residual && i < 3) load_res(i + 1, rl[(i + 1) & 1], rr[(i + 1) & 1]);
+        const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
+            float vl = acc[i][0][e] * p.alpha + bL, vr = acc[i][1][e] * p.alpha + bR;
+            if (p.drop_thresh) {
+                vl = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c0 + cl, p.drop_thresh) ? vl * p.drop_scale : 0.f;
+                vr = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c1 + cl, p.drop_thresh) ? vr * p.drop_scale : 0.f;
+            }
+            if (p.residual) { vl += rl[i & 1][e]; vr += rr[i & 1][e]; }
+            Cf[(long)row * p.ldc + c0 + cl] = vl;                         // (a non-temporal store here measured no different)
+            Cf[(long)row * p.ldc + c1 + cl] = vr;
+        }
+    }
+}
 
 // PP_LEAD: half-tiles in flight ahead of the phase that reads them (3..5; the ring of two K-tiles allows up to 6).  PRIO: 1 = raise the
 // wave priority around every MFMA cluster, 2 = static priority for the second group only, 0 = none.  Measured (tools/gemm_bench.py,
@@ -989,129 +1157,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                             (p.act == 0 || p.act == 1 || p.act == 3 || (p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
-            constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
-            char* tl = reinterpret_cast<char*>(wlds);
-            const int cl = lane & 31, h2 = lane >> 5, g4 = lane >> 4, a16 = lane & 15;
-            const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
-            bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-            bf16_t* Xb = reinterpret_cast<bf16_t*>(p.aux_out);
-            typedef s16x4 __attribute__((address_space(3))) * lptr;
-            auto emit = [&](const f32x16& xl, const f32x16& xr, bf16_t* dst, int row0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    union { bf16_t h[4]; uint2 u; } pl, pr;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { pl.h[e] = (bf16_t)xl[4 * q + e]; pr.h[e] = (bf16_t)xr[4 * q + e]; }
-                    *reinterpret_cast<uint2*>(tl + cl * TP + (8 * q + 4 * h2) * 2) = pl.u;
-                    *reinterpret_cast<uint2*>(tl + (32 + cl) * TP + (8 * q + 4 * h2) * 2) = pr.u;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // this lane's four 8-column groups of its row: columns c0 + 8 (g4 >> 1) + {0, 16, 128, 144} (c1 = c0 + 128): one
-                // address, immediate offsets
-                bf16_t* drow = dst + (long)(row0 + (g4 & 1) * 16 + a16) * p.ldc + c0 + (g4 >> 1) * 8;
-                const char* src0 = tl + ((g4 >> 1) * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const char* src = src0 + sidx * 16 * TP;         // staged column octet (g4 >> 1) + 2 sidx: 0-3 left fragment, 4-7 right
-                    union { struct { s16x4 lo, hi; } s; u32x4 v; } u;
-                    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
-                    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 4 * TP));
-                    *reinterpret_cast<u32x4*>(drow + (sidx & 1) * 16 + (sidx >> 1) * 128) = u.v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            };
-            if (p.act == 4) {
-                // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major
-                // like the output: it takes the reverse trip - 16-byte row-major loads, staged [row][column], and ds_read_b64_tr_b16
-                // hands lane (column c) the 4 consecutive rows of each accumulator register group.  The loads of block i + 1 are
-                // requested before the stores of block i.
-                constexpr int PA = 144;                              // bytes per staged row (64 columns x 2 B + 16 B pad)
-                const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux);
-                const int trow = (g4 & 1) * 16 + a16;
-                const bf16_t* arow = Ab + (long)(m0 + grp * 64 + trow) * p.ldc + c0 + (g4 >> 1) * 8;
-                u32x4 ax[2][4];
-                auto load_aux = [&](int i, u32x4 (&dst)[4]) {
-                    const bf16_t* a_i = arow + (long)((i >> 1) * 128 + (i & 1) * 32) * p.ldc;
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx) dst[sidx] = *reinterpret_cast<const u32x4*>(a_i + (sidx & 1) * 16 + (sidx >> 1) * 128);
-                };
-                load_aux(0, ax[0]);
-                float sL = 0.f, sR = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < 3) load_aux(i + 1, ax[(i + 1) & 1]);
-#pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx)
-                        *reinterpret_cast<u32x4*>(tl + trow * PA + ((g4 >> 1) + 2 * sidx) * 16) = ax[i & 1][sidx];
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    f32x16 l, r;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const char* src = tl + (8 * q + 4 * h2 + (a16 >> 2)) * PA + (((cl >> 4) * 16) + (a16 & 3) * 4) * 2;
-                        const s16x4 tL = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
-                        const s16x4 tR = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 64));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float al = __uint_as_float((unsigned)(unsigned short)tL[e] << 16), ar = __uint_as_float((unsigned)(unsigned short)tR[e] << 16);
-                            l[4 * q + e] = (acc[i][0][4 * q + e] * p.alpha + bL) * al;
-                            r[4 * q + e] = (acc[i][1][4 * q + e] * p.alpha + bR) * ar;
-                            sL += l[4 * q + e]; sR += r[4 * q + e];
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
-                }
-                if (p.colsum) {
-                    sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
-                    if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
-                }
-            } else if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x16 l, r;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { l[e] = acc[i][0][e] * p.alpha + bL; r[e] = acc[i][1][e] * p.alpha + bR; }
-                    emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
-                }
-            } else if (p.act == 3 && Xb) {     // the training forward of fc1: GELU stored, GELU' saved - unrolled (static accumulator indices)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x16 l, r, dl, dr;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float d0, d1;
-                        l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
-                        r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
-                        dl[e] = d0; dr[e] = d1;
-                    }
-                    const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
-                    emit(l, r, Cb, row0);
-                    emit(dl, dr, Xb, row0);
-                }
-            } else
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                f32x16 l = acc[0][0], r = acc[0][1];
-#pragma unroll
-                for (int ii = 1; ii < 4; ++ii)
-                    if (ii == i) { l = acc[ii][0]; r = acc[ii][1]; }
-                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
-                f32x16 dl, dr;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float vl = l[e] * p.alpha + bL, vr = r[e] * p.alpha + bR;
-                    dl[e] = vl; dr[e] = vr;                          // act 1: the saved pre-activation
-                    if (p.act == 1) { vl = gelu_poly(vl); vr = gelu_poly(vr); }
-                    else if (p.act == 3) { float d0, d1; vl = gelu_poly_grad(vl, d0); vr = gelu_poly_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
-                    l[e] = vl; r[e] = vr;
-                }
-                emit(l, r, Cb, row0);
-                if (p.act != 0 && Xb) emit(dl, dr, Xb, row0);
-            }
+            pp_epilogue_bf16(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1130,37 +1176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         const bool direct = !atomic && !p.rowscale && !p.aux && p.act == 0 && p.row_group == 0 && !p.colsum && !p.accumulate &&
                             !p.dbg_skip_epilogue && m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (direct) {
-            const int cl = lane & 31, h2 = lane >> 5;
-            const float bL = p.bias ? p.bias[c0 + cl] : 0.f, bR = p.bias ? p.bias[c1 + cl] : 0.f;
-            float* Cf = reinterpret_cast<float*>(p.C);
-            f32x16 rl[2], rr[2];                                     // residual of the current / next fragment pair
-            auto load_res = [&](int i, f32x16& xl, f32x16& xr) {
-                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const long ro = (long)(row0 + (e & 3) + 8 * (e >> 2) + 4 * h2) * p.ldr;
-                    xl[e] = __builtin_nontemporal_load(p.residual + ro + c0 + cl);       // the residual stream is read exactly once here
-                    xr[e] = __builtin_nontemporal_load(p.residual + ro + c1 + cl);
-                }
-            };
-            if (p.residual) load_res(0, rl[0], rr[0]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (p.residual && i < 3) load_res(i + 1, rl[(i + 1) & 1], rr[(i + 1) & 1]);
-                const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h2;
-                    float vl = acc[i][0][e] * p.alpha + bL, vr = acc[i][1][e] * p.alpha + bR;
-                    if (p.drop_thresh) {
-                        vl = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c0 + cl, p.drop_thresh) ? vl * p.drop_scale : 0.f;
-                        vr = dropout_keep(p.drop_seed, (unsigned long long)row * p.N + c1 + cl, p.drop_thresh) ? vr * p.drop_scale : 0.f;
-                    }
-                    if (p.residual) { vl += rl[i & 1][e]; vr += rr[i & 1][e]; }
-                    Cf[(long)row * p.ldc + c0 + cl] = vl;                         // (a non-temporal store here measured no different)
-                    Cf[(long)row * p.ldc + c1 + cl] = vr;
-                }
-            }
+            pp_epilogue_f32_direct(p, acc, m0, c0, c1, grp, lane);
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1210,6 +1226,258 @@ int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     SS_LAUNCH_CHECK("simseg_gemm(ping-pong)");
     return 0;
 }
+
+// =================================================================================================================
+// Persistent ping-pong kernel (round 3): one workgroup per CU walks a list of output tiles.
+//
+// What the per-tile kernel above loses between tiles (profiles/r2_gemm_shapes_and_tile_timeline.txt: K loop 19.0 us, prologue 2.2 us,
+// epilogue 4.1 us per K = 768 tile, and the launch span is ~15 % longer than rounds x tile time): a new workgroup has to be dispatched,
+// its first half-tiles fetched with nothing to do meanwhile, and all 256 CUs store their tiles at the same instants.  Here
+//   * the operand stream never stops: the half-tile ring is fed across tile boundaries - while a tile's last K-tiles are consumed the
+//     copies already fetch the NEXT tile's first half-tiles (the slots the per-tile kernel fills with dummy copies), so a tile's
+//     "prologue" has happened under the previous tile's K loop and epilogue;
+//   * the epilogue runs with those copies in flight / landed, on scratch taken from the ring slots of the K-tile consumed last
+//     (free by construction: the next tile's first K-tile has the other parity, and of the K-tile after it only the B half 0 is staged);
+//   * tiles are dealt out per XCD exactly as the per-tile kernel's dispatch order does (block b works for XCD b % 8 on that XCD's
+//     contiguous chunk of tiles, stride = blocks per XCD), so the L2 sharing pattern is unchanged.
+// Full tiles, no split-K, the two accumulator-layout epilogues only (the host checks); everything else stays on the per-tile kernel.
+// =================================================================================================================
+template <bool TRANS>
+__device__ __forceinline__ unsigned pp2_lane_off(int piece, int lane, long ld) {
+    if (!TRANS) {                               // [rows][K]: 8 rows x 128 B per 1-KiB piece, swizzled 16-byte chunk
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ kc_swz<64>(r);
+        return (unsigned)((long)r * ld * 2 + c * 16);
+    } else {                                    // [K][rows]: 4 k-rows x 256 B per piece
+        const int kr = piece * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        return (unsigned)((long)kr * ld * 2 + c * 16);
+    }
+}
+
+struct PP2Item { int m0, n0, ntile; const char* a0; const char* b0; };
+
+template <bool TA, bool TB>
+__device__ __forceinline__ PP2Item pp2_item(const GemmParams& p, int t, int tiles_n) {
+    PP2Item it;
+    it.m0 = (t / tiles_n) << 8;
+    it.n0 = (t % tiles_n) << 8;
+    it.ntile = p.K >> 6;
+    it.a0 = static_cast<const char*>(p.A) + (TA ? (long)it.m0 * 2 : (long)it.m0 * p.lda * 2);
+    it.b0 = static_cast<const char*>(p.B) + (TB ? (long)it.n0 * 2 : (long)it.n0 * p.ldb * 2);
+    return it;
+}
+
+// SCHED (where a phase's two global->LDS copies are issued; the load segment of a phase - fragment reads + copies + waits - measured
+// longer than the 8-MFMA segment it is supposed to hide under): 0 = both in the load segment (the per-tile kernel's order), 1 = both
+// inside the wave's own MFMA cluster, 2 = one and one, 3 = both in the load segment but ahead of the fragment reads.
+template <typename TO, bool TA, bool TB, int SCHED = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = p.N >> 8;
+    const int total = tiles_n * (p.M >> 8);
+    // XCD x = blockIdx % 8 owns a contiguous chunk of the tile list (xcd_remap's split); its blocks take every stride-th tile of it
+    const int stride = (int)gridDim.x >> 3;
+    const int x = blockIdx.x & 7;
+    int ord = blockIdx.x >> 3;
+    const int cq = total >> 3, cr = total & 7;
+    const int cnt = cq + (x < cr ? 1 : 0);
+    const int base = x < cr ? x * (cq + 1) : cr * (cq + 1) + (x - cr) * cq;
+    if (ord >= cnt) return;                                          // (uniform per block)
+    const long astep = TA ? 64 * p.lda * 2 : 128, bstep = TB ? 64 * p.ldb * 2 : 128;      // one K-tile further
+    const long ahalf = TA ? 256 : 128 * p.lda * 2, bhalf = TB ? 256 : 128 * p.ldb * 2;    // operand half 1
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = pp2_lane_off<TA>(wave * 2 + i, lane, p.lda);
+        offB[i] = pp2_lane_off<TB>(wave * 2 + i, lane, p.ldb);
+        asm volatile("" : "+v"(offA[i]), "+v"(offB[i]));
+    }
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds;
+    PPFrag<TA, 2> fra;
+    PPFrag<TB, 1> frb;
+    fra.init(0, grp * 64, lane);
+    frb.init(PP_BREG, wn * 32, lane);
+
+    PP2Item cur = pp2_item<TA, TB>(p, base + ord, tiles_n);
+    bool has_next = ord + stride < cnt;
+    PP2Item nxt = pp2_item<TA, TB>(p, base + (has_next ? ord + stride : ord), tiles_n);
+    // staging state: the K-tile whose half-tiles are being requested
+    const char* sA = cur.a0;
+    const char* sB = cur.b0;
+    int krem = cur.ntile - 1;                                        // K-tiles of the staged tile after this one
+    bool nxt_ok = has_next;                                          // the next tile has not been entered by the staging yet
+    unsigned spar = 0;                                               // ring parity of the staged K-tile
+    bool sdummy = false;
+    unsigned cpar = 0;                                               // ring parity of the K-tile being consumed
+
+#define PP2_PIECE(KIND, I)                                                                                            \
+    {                                                                                                                 \
+        const char* sb_ = ((KIND) & 1) ? sA + ((KIND) >> 1) * ahalf : sB + ((KIND) >> 1) * bhalf;                     \
+        const unsigned dst_ = lds0 + wave * 2048 + (I) * 1024 +                                                       \
+                              (sdummy ? PP_DUMMY : (((KIND) & 1) ? 0 : PP_BREG) + (spar * 2 + ((KIND) >> 1)) * PP_HALF); \
+        pp_glds16(((KIND) & 1) ? offA[I] : offB[I], sb_, dst_);                                                       \
+    }
+#define PP2_STAGE(KIND) PP2_PIECE(KIND, 0) PP2_PIECE(KIND, 1)
+#define PP2_ADVANCE()                                                                    \
+    {                                                                                    \
+        if (krem > 0) { --krem; sA += astep; sB += bstep; }                              \
+        else if (nxt_ok) { sA = nxt.a0; sB = nxt.b0; krem = nxt.ntile - 1; nxt_ok = false; } \
+        else sdummy = true;                                                              \
+        spar ^= 1u;                                                                      \
+    }
+    u32x4 fa[8], fb0[4], fb1[4];
+#define PP_READ_A(HALF)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                               \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) fa[i_ * 4 + kk_] = fra.read(lds, (HALF) * PP_HALF, i_, kk_);
+#define PP_READ_B(FB, HALF) \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) FB[kk_] = frb.read(lds, (HALF) * PP_HALF, 0, kk_);
+#define PP_MMA(RH, CH, FB, KK, I) mma<bf16_t>(acc[2 * (RH) + (I)][CH], fa[(I) * 4 + (KK)], FB[KK]);
+    // the wave group's 8 MFMAs of a phase; copies placed inside the cluster go behind the 2nd / 5th MFMA (the matrix pipe has work queued)
+#define PP_CLUSTER(RH, CH, FB, KIND, PRE)                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    PP_MMA(RH, CH, FB, 0, 0) PP_MMA(RH, CH, FB, 0, 1)                                                \
+    if (SCHED == 1) { __builtin_amdgcn_sched_barrier(0); PRE PP2_PIECE(KIND, 0) __builtin_amdgcn_sched_barrier(0); } \
+    PP_MMA(RH, CH, FB, 1, 0) PP_MMA(RH, CH, FB, 1, 1) PP_MMA(RH, CH, FB, 2, 0)                       \
+    if (SCHED == 1 || SCHED == 2) { __builtin_amdgcn_sched_barrier(0); PP2_PIECE(KIND, 1) __builtin_amdgcn_sched_barrier(0); } \
+    PP_MMA(RH, CH, FB, 2, 1) PP_MMA(RH, CH, FB, 3, 0) PP_MMA(RH, CH, FB, 3, 1)                       \
+    /* the cluster's results are "used" here: without this the optimiser sinks the MFMAs (pure register operations) out of the */ \
+    /* priority / barrier bracket into the next phase's load segment */                               \
+    asm volatile("" : "+v"(acc[2 * (RH)][CH]), "+v"(acc[2 * (RH) + 1][CH]));                          \
+    __builtin_amdgcn_s_setprio(0);
+    // one phase: fragment reads of half-tile m + 1, two copies of half-tile m + 5, wait until half-tile m + 2 has landed (the
+    // half-tiles requested after it may stay in flight), then this wave group's 8 MFMAs between two workgroup barriers.  PRE: the
+    // staging state's step to the next K-tile, ahead of the first copy of a B half 0.
+#define PP_PHASE(READS, KIND, PRE, RH, CH, FB)                                                 \
+    {                                                                                          \
+        if (SCHED == 3) { PRE PP2_STAGE(KIND) }                                                \
+        READS                                                                                  \
+        if (SCHED == 0) { PRE PP2_STAGE(KIND) }                                                \
+        if (SCHED == 2) { PRE PP2_PIECE(KIND, 0) }                                             \
+        wait_vm<SCHED == 1 ? 4 : (SCHED == 2 ? 5 : 6)>();                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        __builtin_amdgcn_s_barrier();                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        PP_CLUSTER(RH, CH, FB, KIND, PRE)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        __builtin_amdgcn_s_barrier();                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+
+    f32x16 acc[4][2];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero;
+
+    // ---- prologue (first tile only): half-tiles 0..4 requested
+    PP2_STAGE(0) PP2_STAGE(1) PP2_STAGE(2) PP2_STAGE(3)
+    PP2_ADVANCE()
+    PP2_STAGE(0)
+
+    for (;;) {
+        // ---- top of a tile.  Its first five half-tiles were requested by the prologue / during the previous tile's last phases: all
+        // landed after this wait (as are the previous epilogue's stores: vmcnt counts both); after the barrier every wave's copies are
+        // visible and the epilogue's scratch slots are free again.  The wait is ALSO issued in its builtin form: the compiler's own
+        // wait-count pass cannot see the inline-asm waits, and with loads / stores of the epilogue or register spills pending on a path
+        // into the K loop it puts a vmcnt(0) in front of the loop's first fragment read, where it would drain the copy ring on every
+        // trip.  The K loop's per-lane state is "used" first, so that anything the register allocator spilled around the epilogue is
+        // reloaded ahead of the wait.
+        asm volatile("" : "+v"(offA[0]), "+v"(offA[1]), "+v"(offB[0]), "+v"(offB[1]));
+        fra.pin(); frb.pin();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_READ_B(fb0, 0)
+        if (grp == 1) __builtin_amdgcn_s_barrier();                 // the second group runs one barrier behind the first
+        for (int tt = 0; tt < cur.ntile; ++tt) {
+            PP_PHASE(PP_READ_A(0), 1, , 0, 0, fb0)
+            PP_PHASE(PP_READ_B(fb1, 1), 2, , 0, 1, fb1)
+            PP_PHASE(PP_READ_A(1), 3, , 1, 1, fb1)
+            frb.toggle(2 * PP_HALF);
+            PP_PHASE(PP_READ_B(fb1, 0), 0, PP2_ADVANCE(), 1, 0, fb0)
+            fra.toggle(2 * PP_HALF);
+            cpar ^= 1u;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb0[kk] = fb1[kk];
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();                 // both groups have left the tile's last phase
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue.  Scratch: the ring slots of the K-tile consumed last (parity cpar ^ 1): A halves 0 / 1 (32 KiB, waves 0-6) and B
+        // half 1 (wave 7); the copies in flight write the other parity and this parity's B half 0 only.
+        const int c0 = cur.n0 + wn * 32, c1 = c0 + 128;
+        if constexpr (sizeof(TO) == 2) {
+            const unsigned lp = cpar ^ 1u;
+            char* tl = lds + (wave < 7 ? lp * (2 * PP_HALF) + wave * 4608 : PP_BREG + (lp * 2 + 1) * PP_HALF);
+            pp_epilogue_bf16(p, acc, tl, cur.m0, c0, c1, grp, lane);
+        } else {
+            pp_epilogue_f32_direct(p, acc, cur.m0, c0, c1, grp, lane);
+        }
+        if (!has_next) break;
+        cur.m0 = nxt.m0; cur.n0 = nxt.n0; cur.ntile = nxt.ntile;
+        ord += stride;
+        has_next = ord + stride < cnt;
+        nxt = pp2_item<TA, TB>(p, base + (has_next ? ord + stride : ord), tiles_n);
+        nxt_ok = has_next;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = zero;
+    }
+    wait_vm<0>();                                                    // (dummy copies of the last tile's tail)
+#undef PP_PHASE
+#undef PP2_STAGE
+#undef PP2_PIECE
+#undef PP_MMA
+#undef PP2_ADVANCE
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_CLUSTER
+}
+
+// host side: does this problem qualify for the persistent kernel (the conditions of its two epilogues, full tiles, more than one round)?
+template <typename TO>
+bool pp2_ok(const GemmParams& p, int splitk) {
+    if (splitk > 1 || p.M % 256 || p.N % 256 || p.K % 64 || p.K < 128) return false;
+    if (p.rowscale || p.row_group || p.dbg_skip_epilogue || p.dbg_trace) return false;
+    const long tiles = (long)(p.M / 256) * (p.N / 256);
+    if (tiles <= 256) return false;                                  // one round: nothing to overlap
+    bool vec = (p.ldc % 8 == 0) && (((uintptr_t)p.C) % 16 == 0);
+    if (p.bias) vec = vec && (((uintptr_t)p.bias) % 16 == 0);
+    if (p.aux) vec = vec && (((uintptr_t)p.aux) % 16 == 0);
+    if (p.aux_out) vec = vec && (((uintptr_t)p.aux_out) % 16 == 0);
+    if (sizeof(TO) == 2)
+        return vec && !p.residual && !p.drop_thresh && (p.act == 0 || p.act == 1 || p.act == 3 || (p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum);
+    return !p.aux && p.act == 0 && !p.colsum && !p.accumulate;
+}
+
+template <typename TO, bool TA, bool TB, int SCHED = 0>
+int launch_pp2(const GemmParams& p, hipStream_t stream) {
+    constexpr int SMEM = 9 * PP_HALF;
+    static bool configured = false;
+    static int blocks = 0;
+    auto kern = gemm_pp2_kernel<TO, TA, TB, SCHED>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            return simseg_set_error("simseg_gemm: cannot read the CU count");
+        blocks = cus & ~7;                                           // one workgroup per CU (144 KiB of LDS each), a multiple of the 8 XCDs
+        configured = true;
+    }
+    GemmParams q = p;
+    q.ksplit = p.K / 64; q.nsplit = 1;
+    hipLaunchKernelGGL(kern, dim3(blocks, 1, 1), dim3(512), SMEM, stream, q);
+    SS_LAUNCH_CHECK("simseg_gemm(persistent ping-pong)");
+    return 0;
+}
+
 
 
 // Debug / benchmarking selectors.  Thread-local: the entry points are otherwise stateless and re-entrant, and a selector set by a
@@ -1391,6 +1659,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // (measured, tools/gemm_mid_bench.py: the ping-pong kernel is ahead of the 128x128 one from ~96 of its tiles on - e.g. the packed text
     //  tower's ~22 k x 768 problems, 255 tiles: 34 vs 52 us at K = 768, 98 vs 151 us at K = 3072)
     if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 96) ? 3 : 1;
+    if (v >= 10 && v <= 13 && !(big_ok && !TA)) v = 1;
     // one round of 128x128 tiles (more than the small-problem kernel takes, at most a block per CU): the ring variant's three slabs in
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -1409,7 +1678,28 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     }
     if (!big_ok) v = 1;
     g_gemm_last_variant = v;
-    if (v == 3) return launch_pp<TO, TA, TB>(p, splitk, s);
+    if (v == 3 || (v >= 10 && v <= 13)) {
+        // more than one round of full tiles with an accumulator-layout epilogue: the persistent kernel (10 forces it wherever it
+        // applies, 3 forces the per-tile kernel - A/B runs)
+        // Opt-in only (variant 10; 11-13 its schedule experiments).  Measured (profiles/r3_gemm_persistent_ab.txt): +6 % over the
+        // per-tile kernel on the training shapes in isolation, +1-3 % inside a single-stream training step - and -6.7 % on the default
+        // two-stream step (100.1 vs 93.8 ms): a persistent launch owns every CU for its whole duration (512 threads x 256 VGPRs, 144 KiB
+        // of LDS per CU: nothing co-resides), so the other tower's kernels - GEMM tiles, LayerNorm, attention - no longer slip into
+        // the tails and memory-bound phases of this tower's; the per-tile kernel hands its CUs back after every tile.
+        if constexpr (!TA) {
+            if (g_gemm_variant >= 10 && pp2_ok<TO>(p, splitk)) {
+                g_gemm_last_variant = 10;
+                switch (g_gemm_variant) {           // 11..13: schedule experiments (see SCHED)
+                    case 11: return launch_pp2<TO, TA, TB, 1>(p, s);
+                    case 12: return launch_pp2<TO, TA, TB, 2>(p, s);
+                    case 13: return launch_pp2<TO, TA, TB, 3>(p, s);
+                    default: return launch_pp2<TO, TA, TB, 0>(p, s);
+                }
+            }
+        }
+        g_gemm_last_variant = 3;
+        return launch_pp<TO, TA, TB>(p, splitk, s);
+    }
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
     return launch<bf16_t, TO, TA, TB>(p, splitk, s);
 }

@@ -81,7 +81,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
         e1.record()
         kind = ("f32" if a.dtype == torch.float32 else "bf16") + "_" + ("t" if trans_a else "n") + ("n" if trans_b else "t")
         kind += "_o32" if out.dtype == torch.float32 else "_o16"
-        kind += {1: "", 2: "_L", 3: "_P", 4: "_S", 5: "_R", 8: "_X", 9: "_Y"}[raw("simseg_gemm_last_variant")]      # the kernel the library actually launched
+        kind += {1: "", 2: "_L", 3: "_P", 4: "_S", 5: "_R", 8: "_X", 9: "_Y", 10: "_Q"}[raw("simseg_gemm_last_variant")]      # the kernel the library actually launched
         PROFILE.append((kind, 2.0 * M * N * K, e0, e1))
     return out
 

@@ -73,6 +73,23 @@ def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand
     return {"pred": pred, "hist": hist, "cand_idx": cand_idx, "cand_score": cand_score, "threshold": thr, "masks": masks}
 
 
+def eval_batch(model, image, label, text, top_cls_num, hist=None, crf=True, mean=None, std=None, sim_dtype=None, refine=None,
+               want_pred=False):
+    """One batch of the zero-shot segmentation evaluation, everything on the device (tools/seg_evaluation.py:99-170 for every image of
+    the batch at once): towers -> pooled embedding + projected patch tokens -> similarity map for all classes -> segment().
+    image [B,3,S,S] normalised network input, label [B,H,W] uint8, text [C,512] unit-norm class embeddings.  crf: run the DenseCRF on
+    the de-normalised input (image * std + mean, :104) as the reference does; hist [3,C] int64 accumulates."""
+    from .heads import patch_text_similarity
+    feats = model.forward_image_feature(image)                    # [B, n*n, D]
+    pooled = model.forward_image_project(feats)                   # [B, 512]
+    n = int(round(feats.shape[1] ** 0.5))
+    sim = patch_text_similarity(model.image_projection(feats), text, compute_dtype=sim_dtype)
+    raw = None
+    if crf and refine is None:
+        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    return segment(sim, ops.gemm(pooled.float(), text), label, n, top_cls_num, hist=hist, want_pred=want_pred, refine=refine, images_u8=raw)
+
+
 def iou_from_hist(hist):
     """hist [3,C] int64 -> (per-class IoU float64 with NaN where the class never occurs, mean over non-NaN) as :172-173."""
     inter, pred, label = hist[0].double(), hist[1].double(), hist[2].double()

@@ -213,6 +213,67 @@ def test_gemm_pingpong_accumulator_layout_epilogues(ops, tb, M, N, K):
     assert float(((d3.abs() < 1e-6) != (d1.abs() < 1e-6)).float().mean()) < 1e-3          # the same dropout mask
 
 
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(256 * 90, 768, 768), (256 * 33, 2304, 192), (256 * 131, 768, 320), (256 * 9, 256 * 30, 128)])
+def test_gemm_persistent_pingpong_kernel(ops, tb, M, N, K):
+    """The persistent 256x256 ping-pong kernel (one workgroup per CU walks its XCD's tile list, operand copies running across tile
+    boundaries, epilogue scratch in the ring slots of the K-tile consumed last): every epilogue it carries, on tile counts that leave
+    blocks with 1, 2, ... tiles and an uneven split over the XCDs, odd and even K-tile counts (the ring parity at a tile boundary),
+    against fp64 torch and - bit for bit, same MFMA order - against the per-tile kernel."""
+    from simseg_amd.lib import raw
+    a = _rand(M, K, seed=1, dtype=torch.bfloat16)
+    b = _rand(*((K, N) if tb else (N, K)), seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    ref = (a.double() @ (b.double() if tb else b.double().T)).float()
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    aux = _rand(M, N, seed=5, dtype=torch.bfloat16)
+    x = (ref + bias).requires_grad_(True)
+    F.gelu(x).backward(torch.ones_like(x))
+    results = {}
+    for variant in (10, 3):
+        ops.set_gemm_variant(variant)
+        try:
+            r = {}
+            r["plain"] = ops.gemm(a, b, trans_b=tb)
+            assert raw("simseg_gemm_last_variant") == variant, (variant, raw("simseg_gemm_last_variant"))
+            if variant == 10:
+                for sched in (11, 12, 13):          # the schedule experiments compute the same thing
+                    ops.set_gemm_variant(sched)
+                    assert torch.equal(ops.gemm(a, b, trans_b=tb), r["plain"]), sched
+                ops.set_gemm_variant(variant)
+            r["bias_alpha"] = ops.gemm(a, b, trans_b=tb, bias=bias, alpha=0.5)
+            pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            r["gelu"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=1, aux_out=pre)
+            r["gelu_pre"] = pre
+            d = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            r["gelu3"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=3, aux_out=d)
+            r["gelu3_d"] = d
+            r["gelu3_noaux"] = ops.gemm(a, b, trans_b=tb, bias=bias, act=3)
+            cs = torch.zeros(N, device="cuda")
+            r["times_aux"] = ops.gemm(a, b, trans_b=tb, act=4, aux=aux, colsum=cs)
+            r["times_aux_colsum"] = cs
+            r["f32_res"] = ops.gemm(a, b, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32)
+            assert raw("simseg_gemm_last_variant") == variant
+            r["f32_res_drop"] = ops.gemm(a, b, trans_b=tb, bias=bias, residual=res, out_dtype=torch.float32, drop_seed=7, drop_p=0.1)
+            results[variant] = r
+        finally:
+            ops.set_gemm_variant(0)
+    want = {"plain": ref, "bias_alpha": ref * 0.5 + bias, "gelu": F.gelu(ref + bias), "gelu_pre": ref + bias, "gelu3": F.gelu(ref + bias),
+            "gelu3_d": x.grad, "gelu3_noaux": F.gelu(ref + bias), "times_aux": ref * aux.float(), "f32_res": ref + bias + res}
+    for k, w in want.items():
+        _close(results[10][k], w, 1e-5 if k.startswith("f32") else 1e-2, f"persistent {k}")
+    _close(results[10]["times_aux_colsum"], (ref * aux.float()).sum(0), 2e-4, "column sums")
+    for k in results[10]:
+        if k.endswith("colsum"):
+            continue                                                          # (atomic order differs)
+        assert torch.equal(results[10][k], results[3][k]), f"persistent vs per-tile kernel: {k} differs"
+    # the persistent kernel is opt-in (it owns every CU for its whole launch: slower under the two-stream tower schedule)
+    ops.gemm(a, b, trans_b=tb)
+    assert raw("simseg_gemm_last_variant") == (3 if K >= 768 else 1)       # (short contractions stay on the 128x128 kernel)
+    # repeated launches are independent (no state carried in the ring / scratch between launches)
+    again = ops.gemm(a, b, trans_b=tb, bias=bias, alpha=0.5)
+    assert torch.equal(again, results[10]["bias_alpha"])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gather_rows(ops, dtype):
     """Row gather with -1 -> zero row (packing / unpacking the real tokens of a ragged caption batch)."""

@@ -1,0 +1,162 @@
+"""The north-star gate "mIoU within +-0.1" (BASELINE.json), end to end: synthetic VOC-shaped images -> towers -> projection + LoDA pooled
+embedding -> patch x class-text similarity map -> candidate classes -> min-max map -> DenseCRF -> 7x7 dilate / erode -> resize ->
+score-weighted argmax -> accumulated intersect / union histograms -> per-class IoU and mIoU (tools/seg_evaluation.py:99-181), once
+through the HIP pipeline (simseg_amd.segpost.eval_batch, what tools/seg_eval_device.py runs) and once through the reference's
+per-image loop evaluated with the oracle (oracle/simseg_ref towers and heads, oracle/segpost_ref, oracle/crf_ref).
+
+The labels are made FROM the oracle's own predictions (shifted by a few pixels, 10 % of the pixels relabelled, 5 % ignored): with
+random weights a random label map would put every IoU near zero and hide pipeline differences; this way the classes the model predicts
+have IoUs of 60-90 % and a flipped candidate class or a displaced CRF boundary moves the metric by whole points.  Both pipelines are
+scored against the same labels; the gate is |delta mIoU| <= 0.1 percentage points and per-class agreement, in exact fp32 and in the
+bf16 evaluation mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # configs/clip/*.yaml transforms.normalize
+
+
+def _voc_like(B, size, seed):
+    """Structured colour fields: a smooth background gradient, a few coloured rectangles / ellipses ("objects"), sensor noise.
+    Returns uint8 RGB [B,size,size,3] and the normalised network input [B,3,size,size]."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    imgs = np.empty((B, size, size, 3), np.float32)
+    for b in range(B):
+        base = np.stack([xx * (200.0 / size) + 20, yy * (180.0 / size) + 30, (xx + yy) * (90.0 / size) + 40], -1)
+        for _ in range(3 + b % 2):
+            cy, cx = rng.uniform(0.2, 0.8, 2) * size
+            ry, rx = rng.uniform(0.08, 0.3, 2) * size
+            col = rng.uniform(0, 255, 3)
+            if rng.random() < 0.5:
+                m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+            else:
+                m = (np.abs(yy - cy) < ry) & (np.abs(xx - cx) < rx)
+            base[m] = col
+        imgs[b] = base + rng.normal(0, 6, base.shape)
+    u8 = np.clip(imgs, 0, 255).astype(np.uint8)
+    x = torch.from_numpy(u8).float().permute(0, 3, 1, 2) / 255.0
+    x = (x - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
+    return u8, x.contiguous()
+
+
+def _build(vit_tag, vit_dim, bert_tag, bert_dim, size, seed):
+    from simseg.core.config import update_cfg
+    from simseg.models import PIPELINE
+    from simseg.tasks.clip.config import task_cfg_init_fn, update_clip_config
+    from simseg.utils import build_from_cfg
+    argv = [f"transforms.input_size={size}", f"model.image_encoder.tag={vit_tag}", f"model.image_encoder.embedding_dim={vit_dim}",
+            "model.image_encoder.pretrained=False", f"model.text_encoder.tag={bert_tag}", f"model.text_encoder.embedding_dim={bert_dim}",
+            "model.text_encoder.pretrained=False"]
+    cfg = update_cfg(task_cfg_init_fn, os.path.join(REPO, "configs/clip/simseg.vit-s.yaml"), argv, update_clip_config)
+    torch.manual_seed(seed)
+    return build_from_cfg(cfg.model.name, cfg, PIPELINE)
+
+
+def _oracle_predictions(ref, x, u8, text, top_cls_num):
+    """The reference's per-image loop (tools/seg_evaluation.py:99-163) with the oracle's pieces -> pred [B,H,W] int64."""
+    from oracle import crf_ref as CR
+    from oracle import segpost_ref as SR
+    from oracle import simseg_ref as R
+    B, _, S, _ = x.shape
+    n, C = S // 16, text.shape[0]
+    preds = np.zeros((B, S, S), np.int64)
+    visited = 0
+    with torch.no_grad():
+        for b in range(B):                                                       # batch size 1, as the tool runs
+            feats = ref.forward_image_feature(x[b:b + 1])                        # :99
+            pooled = ref.forward_image_project(feats)                            # :100
+            tok = ref.image_projection(feats)                                    # :101-102
+            sim = R.seg_similarity(tok, text)[0]                                 # :112 + :136 for every class
+            scores = R.seg_image_scores(pooled, text)[0]                         # :119
+            idx, sc, _ = SR.select_candidates(scores, top_cls_num)               # :121-133, :145-146
+            temp = np.zeros((C, S, S))
+            for k, c in enumerate(idx):
+                if c < 0:
+                    continue
+                visited += 1
+                norm, _ = SR.normalised_map(sim[:, c].numpy(), n)                # :135-149
+                m = (CR.dense_crf(u8[b], norm) * 255).astype(np.uint8)           # :153
+                m = SR.morph7_fast(SR.morph7_fast(m, False), True)               # :155-157
+                temp[c] = SR.resize_nearest(m, S, S).astype(np.float64) * sc[k]  # :159-160
+            preds[b] = temp.argmax(0)                                            # :163
+    return preds, visited
+
+
+def _labels_from(preds, seed, C):
+    """Ground truth that the predictions agree with only partly: shifted, 10 % relabelled in blocks, 5 % ignored."""
+    rng = np.random.default_rng(seed)
+    lab = np.roll(preds, (5, -4), (1, 2)).copy()
+    B, H, W = lab.shape
+    blocks = rng.random((B, H // 16, W // 16)) < 0.10
+    newc = rng.choice(np.unique(preds), (B, H // 16, W // 16))                 # (classes that never occur stay absent: NaN IoU, not 0)
+    up = lambda a: np.repeat(np.repeat(a, 16, 1), 16, 2)                         # noqa: E731
+    lab = np.where(up(blocks), up(newc), lab)
+    lab[rng.random(lab.shape) < 0.05] = 255
+    return lab.astype(np.uint8)
+
+
+def _miou(hist3):
+    """tools/seg_evaluation.py:172-176 + simseg/utils/metrics.py:85-99: IoU per class from the accumulated areas, nanmean, in percent."""
+    inter, pred, label = [np.asarray(h, np.float64) for h in hist3]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        iou = inter / (pred + label - inter)
+    return iou * 100.0, float(np.nanmean(iou) * 100.0)
+
+
+@pytest.mark.parametrize("case", ["tiny_288", "vit_s_288"])
+def test_miou_gate_hip_pipeline_vs_oracle_loop(case, monkeypatch):
+    from oracle import segpost_ref as SR
+    from oracle import simseg_ref as R
+    from simseg_amd import segpost
+    if case == "tiny_288":
+        vit, vdim, bert, bdim, B = "vit_test_patch16", 128, "bert-test", 128, 5
+    else:
+        vit, vdim, bert, bdim, B = "vit_small_patch16_224_in21k", 384, "bert-test", 128, 2
+    S, C, top = 288, 21, 10
+    u8, x = _voc_like(B, S, seed=17)
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(C, 512, generator=g), dim=-1)
+    model = _build(vit, vdim, bert, bdim, S, seed=5).eval()
+    ref = R.RefCLIP(vit, bert, img_size=S)
+    missing, unexpected = ref.load_state_dict(model.state_dict(), strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    ref.eval()
+    model = model.cuda()
+
+    want_pred, visited = _oracle_predictions(ref, x, u8, text, top)
+    assert visited >= B, "the scene must exercise the candidate / CRF path"
+    labels = _labels_from(want_pred, seed=9, C=C)
+    hist_ref = np.zeros((3, C))
+    for b in range(B):
+        hist_ref += np.stack([h.numpy() for h in SR.intersect_and_union(want_pred[b], labels[b], C)])
+    iou_ref, miou_ref = _miou(hist_ref)
+    present = ~np.isnan(iou_ref)
+    assert present.sum() >= 3 and 30.0 < miou_ref < 99.0, (miou_ref, iou_ref)       # a metric that can move
+
+    mean = torch.tensor(MEAN, device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor(STD, device="cuda").view(1, 3, 1, 1)
+    report = {}
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+        hist = torch.zeros(3, C, device="cuda", dtype=torch.int64)
+        with torch.no_grad():
+            out = segpost.eval_batch(model, x.cuda(), torch.from_numpy(labels).cuda(), text.cuda(), top, hist=hist, crf=True, mean=mean, std=std,
+                                     sim_dtype=torch.bfloat16 if mode == "bf16" else None, want_pred=True)
+        iou, miou = _miou(hist.cpu().numpy())
+        agree = float((out["pred"].cpu().numpy() == want_pred).mean())
+        report[mode] = (miou, miou - miou_ref, agree, np.nanmax(np.abs(iou - iou_ref)[present]))
+        print(f"{case} {mode}: mIoU {miou:.3f} vs oracle loop {miou_ref:.3f} (delta {miou - miou_ref:+.4f} points), pixel agreement {agree:.5f}, "
+              f"largest per-class IoU difference {report[mode][3]:.3f} points over {int(present.sum())} classes present")
+        assert np.array_equal(np.isnan(iou), np.isnan(iou_ref)), "a class appears / disappears"
+    # the gate: BASELINE.json north_star "mIoU within +-0.1" (percentage points, as the reference reports mIoU x 100)
+    assert abs(report["fp32"][1]) <= 0.1, report
+    assert report["fp32"][2] >= 0.999 and report["fp32"][3] <= 0.5, report
+    assert abs(report["bf16"][1]) <= 0.1, report
+    assert report["bf16"][3] <= 1.0, report

@@ -20,10 +20,10 @@ def kind_of(name):
     m = re.search(r"gemm_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)E", name)
     suffix = ""
     if not m:
-        m2 = re.search(r"gemm_(large|pp)_kernelI(DF16b|f)Lb(\d)ELb(\d)E", name)
+        m2 = re.search(r"gemm_(large|pp|pp2)_kernelI(DF16b|f)Lb(\d)ELb(\d)E", name)
         if not m2:
             return None
-        tin, tout, ta, tb, suffix = "DF16b", m2.group(2), m2.group(3), m2.group(4), "_L" if m2.group(1) == "large" else "_P"
+        tin, tout, ta, tb, suffix = "DF16b", m2.group(2), m2.group(3), m2.group(4), {"large": "_L", "pp": "_P", "pp2": "_Q"}[m2.group(1)]
     else:
         tin, tout, ta, tb = m.groups()
     k = ("bf16" if tin == "DF16b" else "f32") + "_" + ("t" if ta == "1" else "n") + ("n" if tb == "1" else "t")

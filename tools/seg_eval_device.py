@@ -146,16 +146,11 @@ def main():
                 st.wait_stream(cur)
                 image.record_stream(st); label.record_stream(st)
                 with torch.cuda.stream(st):
-                    feats = model.forward_image_feature(image)
-                    pooled = model.forward_image_project(feats)
-                    sim = patch_text_similarity(model.image_projection(feats), text)
-                    refine = raw = None
-                    if not args.no_crf:         # the de-normalised input the tool hands to dense_crf (tools/seg_evaluation.py:104)
-                        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
-                        if args.host_crf:
-                            refine, raw = host_crf_refine(raw.cpu().numpy()), None
-                    segpost.segment(sim, ops.gemm(pooled, text), label, n, top_cls_num, hist=hist, want_pred=False, refine=refine,
-                                    images_u8=raw)
+                    refine = None
+                    if args.host_crf and not args.no_crf:
+                        refine = host_crf_refine((((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy())
+                    # (the de-normalised input is what the tool hands to dense_crf, tools/seg_evaluation.py:104)
+                    segpost.eval_batch(model, image, label, text, top_cls_num, hist=hist, crf=not args.no_crf, mean=mean, std=std, refine=refine)
                 count += image.shape[0]
         for st in streams:
             cur.wait_stream(st)
