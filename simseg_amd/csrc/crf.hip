@@ -97,10 +97,23 @@ __device__ __forceinline__ int crf_find(const CrfTable& t, unsigned long long ke
     }
 }
 
-// Permutohedral::init, one thread per pixel (pixel i = y * W + x).  D = 2: (x, y) / sxy;  D = 5: (x, y) / sxy, rgb / srgb.
+// Internal pixel order.  Every per-pixel array of the solver (lattice offsets, barycentric weights, Q, unaries, filter outputs, norms)
+// is indexed by an INTERNAL pixel number; only the kernels that touch the caller's tensors (rgb, prob, mask, q_out) translate it.  With
+// tw = W / 16 > 0 (H and W multiples of 16) the internal order is tile-major - 256 consecutive pixels are one 16 x 16 image tile - so a
+// block's pixels are neighbours in BOTH image directions: the block-level de-duplication of the hash build and of the entry counts sees
+// a fraction of the distinct lattice points that a 256 x 1 strip of a raster row touches (the bilateral kernel is 40 pixels wide: a
+// strip crosses ~6 lattice cells, a tile stays inside one), the point ids drawn in creation order become 2-D local, and so do the
+// gathers / slices / blur neighbours.  tw = 0: raster order (any image size).
+__device__ __forceinline__ int crf_raster(int li, int W, int tw) {
+    if (tw == 0) return li;
+    const int t = li >> 8, w = li & 255;
+    return ((t / tw) * 16 + (w >> 4)) * W + (t % tw) * 16 + (w & 15);
+}
+
+// Permutohedral::init, one thread per (internal) pixel.  D = 2: (x, y) / sxy;  D = 5: (x, y) / sxy, rgb / srgb.
 template <int D>
-__global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int nimg, int H, int W, float inv_sxy, float inv_srgb,
-                                                          CrfTable table, int* __restrict__ off, float* __restrict__ bary,
+__global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* __restrict__ rgb, int nimg, int H, int W, int tw, float inv_sxy,
+                                                          float inv_srgb, CrfTable table, int* __restrict__ off, float* __restrict__ bary,
                                                           int* __restrict__ overflow) {
     // Block-level de-duplication in front of the global table: neighbouring pixels share most of their simplex vertices (a lattice point
     // has ~15 entries), and same-key CAS operations on one global address serialise.  The block's 256 x (D + 1) keys first meet in an LDS
@@ -113,13 +126,13 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
     const long i0 = (long)blockIdx.x * 256 + threadIdx.x;         // pixel of the batch: image i / (H W)
     const bool valid = i0 < (long)nimg * H * W;
     const long i = valid ? i0 : (long)nimg * H * W - 1;
-    const int img = (int)(i / (H * W)), li = (int)(i % (H * W));
+    const int img = (int)(i / (H * W)), li = crf_raster((int)(i % (H * W)), W, tw);
     float f[D];
     f[0] = (float)(li % W) * inv_sxy;
     f[1] = (float)(li / W) * inv_sxy;
     if constexpr (D == 5) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f[2 + c] = (float)rgb[(long)i * 3 + c] * inv_srgb;
+        for (int c = 0; c < 3; ++c) f[2 + c] = (float)rgb[((long)img * H * W + li) * 3 + c] * inv_srgb;
     }
     const float inv_std_dev = sqrtf(2.0f / 3.0f) * (D + 1);
     float elevated[D + 1];
@@ -411,12 +424,12 @@ __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict_
 
 // U = -log([1 - p, p] + 1e-8);  Q = softmax(-U)   (prob [C][N] -> q1 [N][C], u [N][C][2])
 __global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__ prob, float* __restrict__ q1, float* __restrict__ u, long NT, int N,
-                                                       int C) {
+                                                       int C, int W, int tw) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;          // NT = images x N pixels of the batch; prob is [image][C][N]
     if (t >= NT * C) return;
     const long i = t / C;
     const int c = (int)(t % C);
-    const float p = prob[((i / N) * C + c) * N + i % N];
+    const float p = prob[((i / N) * C + c) * N + crf_raster((int)(i % N), W, tw)];
     const float u0 = -logf((1.0f - p) + 1e-8f), u1 = -logf(p + 1e-8f);
     u[t * 2] = u0; u[t * 2 + 1] = u1;
     const float t0 = -u0, t1 = -u1, mx = fmaxf(t0, t1);
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict__ u, const float* __restrict__ fg, const float* __restrict__ fb,
                                                          const float* __restrict__ kng, const float* __restrict__ knb, float wg, float wb,
                                                          float* __restrict__ q1, unsigned char* __restrict__ mask, float* __restrict__ q_out,
-                                                         long NT, int N, int C) {
+                                                         long NT, int N, int C, int W, int tw) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= NT * C) return;
     const long i = t / C;
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict
     const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
     const float q = e1 / (e0 + e1);
     q1[t] = q;
-    const long o = ((i / N) * C + c) * N + i % N;
+    const long o = ((i / N) * C + c) * N + crf_raster((int)(i % N), W, tw);
     if (mask) mask[o] = (e1 / (e0 + e1) > e0 / (e0 + e1)) ? 255 : 0;                          // argmax over [Q0, Q1], ties -> label 0
     if (q_out) q_out[o] = q;
 }
@@ -531,13 +544,13 @@ void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, co
 }
 
 template <int D>
-void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, int W, float sxy, float srgb, int* overflow, float* val0, float* val1,
-               hipStream_t s) {
+void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, int W, int tw, float sxy, float srgb, int* overflow, float* val0,
+               float* val1, hipStream_t s) {
     const long N = (long)nimg * H * W;
     const long nv = N * (D + 1);
     (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)(lt.scap + lt.cap) * sizeof(unsigned long long), s);
     const CrfTable table{lt.hkeys, lt.hid, (unsigned)(lt.scap - 1), (unsigned)(lt.cap - 1)};
-    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, 1.0f / sxy, 1.0f / srgb, table,
+    hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, tw, 1.0f / sxy, 1.0f / srgb, table,
                        lt.off, lt.bary, overflow);
     hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((nv + 4095) / 4096)), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.M);
     hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
@@ -607,16 +620,17 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     crf_carve(L, static_cast<char*>(workspace), NT, N, Ci, lat, val0, val1, q1, u, fg, fb, flags);
     (void)hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
     // the spatial lattice depends on (H, W, sxy) only: built for ONE image, shared by the batch
-    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, sxy_g, 1.0f, flags + 2, val0, val1, s);
-    crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, sxy_b, srgb, flags + 2, val0, val1, s);
+    const int tw = (H % 16 == 0 && W % 16 == 0) ? (int)(W / 16) : 0;       // tile-major internal pixel order where the image tiles evenly
+    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s);
+    crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, tw, sxy_b, srgb, flags + 2, val0, val1, s);
     const long nc = NT * Ci;
-    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci);
+    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci, (int)W, tw);
     for (int it = 0; it < iters; ++it) {
         crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, (int)B, s);
         crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, 1, s);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
-                           q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci);
+                           q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci, (int)W, tw);
     }
     SS_LAUNCH_CHECK("dense_crf");
     return 0;

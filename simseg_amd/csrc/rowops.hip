@@ -288,12 +288,16 @@ __global__ void vit_cls_rows_kernel(const float* __restrict__ cls, const float* 
     x[(long)b * T * D + d] = cls[d] + pos[d];
 }
 // backward: dcls += sum_b dx[b,0,:],  dpos[0] handled by the position column-sum over all rows
+// (blockIdx.y: slices of 16 images - three blocks walking all 512 rows serially, each load a DRAM latency, took 195 us; one atomic per
+//  column and slice)
 __global__ void vit_cls_grad_kernel(const float* __restrict__ dx, float* __restrict__ dcls, int B, int T, int D) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
+    const int b0 = blockIdx.y * 16, b1 = min(B, b0 + 16);
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dx[(long)b * T * D + d];
-    dcls[d] += s;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += dx[(long)b * T * D + d];
+    atomicAdd(dcls + d, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,7 +681,7 @@ extern "C" int simseg_vit_cls_rows(const float* cls, const float* pos, float* x,
 
 extern "C" int simseg_vit_cls_grad(const float* dx, float* dcls, int64_t B, int64_t T, int64_t D, void* stream) {
     SS_CHECK(dx && dcls, "vit_cls_grad: null pointer");
-    hipLaunchKernelGGL(vit_cls_grad_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, STREAM, dx, dcls, (int)B, (int)T, (int)D);
+    hipLaunchKernelGGL(vit_cls_grad_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)((B + 15) / 16)), dim3(256), 0, STREAM, dx, dcls, (int)B, (int)T, (int)D);
     SS_LAUNCH_CHECK("vit_cls_grad");
     return 0;
 }
