@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__
 // rank[e] = position of entry e in its point's list, cnt[m] = list lengths.  A block's 1024 consecutive entries (~170 neighbouring
 // pixels) mostly repeat a few hundred points: they are counted in an LDS table first and each distinct point costs the block ONE global
 // atomicAdd (same-address global atomics serialise; this pass was 25 M of them).  The fill then needs no atomic at all.
-__global__ __launch_bounds__(256) void crf_count_kernel(const int* __restrict__ off, int* __restrict__ cnt, int* __restrict__ rank, long nv) {
+// (hid: the entries still hold hash slots when this kernel starts - translated to dense point ids here, on the way)
+__global__ __launch_bounds__(256) void crf_count_kernel(int* __restrict__ off, const int* __restrict__ hid, int* __restrict__ cnt, int* __restrict__ rank,
+                                                        long nv) {
     constexpr int LSLOTS = 2048, EPT = 4;
     __shared__ int lid[LSLOTS], lcnt[LSLOTS], lbase[LSLOTS];
     for (int t = threadIdx.x; t < LSLOTS; t += 256) { lid[t] = -1; lcnt[t] = 0; }
@@ -270,7 +272,8 @@ __global__ __launch_bounds__(256) void crf_count_kernel(const int* __restrict__ 
         const long e = e0 + 256 * j;
         slot[j] = -1;
         if (e < nv) {
-            const int m = off[e];
+            const int m = hid[off[e] & 0x7fffffff];
+            off[e] = m;
             unsigned sl = ((unsigned)m * 0x9E3779B1u) >> 21;      // 11 bits
             for (;;) {
                 const int prev = atomicCAS(&lid[sl], -1, m);
@@ -319,8 +322,12 @@ __global__ __launch_bounds__(256) void crf_fill_kernel(const int* __restrict__ o
 template <int D>
 __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict__ in, const float* __restrict__ scale, const int* __restrict__ start,
                                                          const int* __restrict__ cnt, const int* __restrict__ ent, const float* __restrict__ entw,
-                                                         float* __restrict__ val, const int* __restrict__ M, int C, long in_stride, long val_stride) {
+                                                         float* __restrict__ val, const int* __restrict__ M, int C, long in_stride, long val_stride,
+                                                         int extra) {
+    // extra = 1: one more channel behind the C channels of `in`, whose input is the constant 1 (times the entry weight): the filter of
+    // the lattice's norm rides along with the first mean-field filter instead of being a filter application of its own
     constexpr int G = D == 2 ? 16 : 8;
+    const int CT = C + extra;
     const int sub = threadIdx.x & (G - 1);
     if (in) in += (long)blockIdx.y * in_stride;                   // blockIdx.y: images that SHARE this lattice (the spatial one), see crf_filter
     val += (long)blockIdx.y * val_stride;
@@ -336,18 +343,18 @@ __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict
             const float w = entw[s0 + j];                         // (already times scale[px] when the filter's input is scaled: entws)
 #pragma unroll
             for (int c = 0; c < CRF_MAXC; ++c)
-                if (c < C) acc[c] += w * (in ? in[px * C + c] : 1.0f);
+                if (c < CT) acc[c] += w * ((in && c < C) ? in[px * C + c] : 1.0f);
         }
 #pragma unroll
         for (int c = 0; c < CRF_MAXC; ++c)
-            if (c < C) {
+            if (c < CT) {
 #pragma unroll
                 for (int o = G / 2; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
             }
         if (live && sub == 0) {
 #pragma unroll
             for (int c = 0; c < CRF_MAXC; ++c)
-                if (c < C) val[(m + 1) * C + c] = acc[c];
+                if (c < CT) val[(m + 1) * CT + c] = acc[c];
         }
     }
 }
@@ -358,11 +365,6 @@ __global__ __launch_bounds__(256) void crf_prescale_kernel(const int* __restrict
                                                            float* __restrict__ entws, long nv) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e < nv) entws[e] = entw[e] * norm[ent[e]];
-}
-
-__global__ __launch_bounds__(256) void crf_offsets_kernel(int* __restrict__ off, const int* __restrict__ hid, long n) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) off[i] = hid[off[i] & 0x7fffffff];
 }
 
 template <int D>
@@ -400,19 +402,21 @@ __global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__
 template <int D>
 __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ val, const float* __restrict__ scale, const int* __restrict__ off,
                                                         const float* __restrict__ bary, float* __restrict__ out, long N, int C, int sqrt_norm,
-                                                        long val_stride, long out_stride) {
+                                                        long val_stride, long out_stride, float* __restrict__ out2) {
+    // out2 != nullptr: the value rows carry C + 1 channels; the last one (the filtered norm, see crf_gather_kernel) goes to out2[i]
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     val += (long)blockIdx.y * val_stride;
     out += (long)blockIdx.y * out_stride;
+    const int CT = C + (out2 ? 1 : 0);
     const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
     float acc[CRF_MAXC];
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
-        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * C;
+        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * CT;
         const float w = bary[(long)i * (D + 1) + r];
-        for (int c = 0; c < C; ++c) acc[c] += w * val[o + c] * alpha;
+        for (int c = 0; c < CT; ++c) acc[c] += w * val[o + c] * alpha;
     }
     const float sc = scale ? scale[i] : 1.0f;
     for (int c = 0; c < C; ++c) {
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict_
         if (sqrt_norm) v = 1.0f / sqrtf(v + 1e-20f);                          // norm = 1 / sqrt(K 1 + 1e-20)
         out[(long)i * C + c] = v;
     }
+    if (out2 && blockIdx.y == 0) out2[i] = acc[C] * sc;                       // (images that share the lattice produce the same value)
 }
 
 // U = -log([1 - p, p] + 1e-8);  Q = softmax(-U)   (prob [C][N] -> q1 [N][C], u [N][C][2])
@@ -504,7 +509,7 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
         lat[k].entw = L.carve<float>(base, nv);
         lat[k].entws = L.carve<float>(base, nv);
     }
-    const long vmax = (N * 6 + 1) * (long)C;
+    const long vmax = (N * 6 + 1) * (long)(C + 1);               // (+1: the constant-one channel of the first mean-field filter)
     val0 = L.carve<float>(base, vmax);
     val1 = L.carve<float>(base, vmax);
     q1 = L.carve<float>(base, N * C);
@@ -526,26 +531,27 @@ unsigned crf_blocks(long work) {
 // one image's and serves every image of the batch through blockIdx.y.
 template <int D>
 void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, long N,
-                int C, int sqrt_norm, int nimg, hipStream_t s) {
-    const long vstride = (N * (D + 1) + 1) * (long)C;
-    (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
-    (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)C * sizeof(float), nimg, s);
+                int C, int sqrt_norm, int nimg, hipStream_t s, float* out2 = nullptr) {
+    const int CT = C + (out2 ? 1 : 0);                          // out2: one more channel, the filter of the constant 1 (-> the lattice's kn)
+    const long vstride = (N * (D + 1) + 1) * (long)CT;
+    (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)CT * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
+    (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)CT * sizeof(float), nimg, s);
     hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent,
-                       scale_in ? lt.entws : lt.entw, val0, lt.M, C, N * C, vstride);
+                       scale_in ? lt.entws : lt.entw, val0, lt.M, C, N * C, vstride, out2 ? 1 : 0);
     float* a = val0;
     float* b = val1;
     for (int j = 0; j <= D; ++j) {
         // lattice points are a fraction of the worst case N (D + 1): a grid-stride launch sized for N / 4 points per channel
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * C), nimg), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, C, vstride);
+        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * CT), nimg), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, CT, vstride);
         float* t = a; a = b; b = t;
     }
     hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((unsigned)((N + 255) / 256), nimg), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm,
-                       vstride, N * C);
+                       vstride, N * C, out2);
 }
 
 template <int D>
 void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, int W, int tw, float sxy, float srgb, int* overflow, float* val0,
-               float* val1, hipStream_t s) {
+               float* val1, hipStream_t s, bool with_kn) {
     const long N = (long)nimg * H * W;
     const long nv = N * (D + 1);
     (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)(lt.scap + lt.cap) * sizeof(unsigned long long), s);
@@ -553,16 +559,16 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, tw, 1.0f / sxy, 1.0f / srgb, table,
                        lt.off, lt.bary, overflow);
     hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((nv + 4095) / 4096)), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.M);
-    hipLaunchKernelGGL(crf_offsets_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.hid, nv);
     hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, table, lt.nb, lt.mmax);
     (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
-    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.cnt, lt.cnt + nv, nv);
+    hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.hid, lt.cnt, lt.cnt + nv, nv);
     hipLaunchKernelGGL(crf_alloc_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);
     hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.ent, lt.entw, nv, D + 1);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
     crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, 1, s);
     hipLaunchKernelGGL(crf_prescale_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.ent, lt.entw, lt.norm, lt.entws, nv);
-    crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, 1, s);
+    // (with_kn = false: the caller's first mean-field filter carries the constant-one channel along and writes kn itself)
+    if (with_kn) crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, 1, s);
 }
 
 // largest |lattice coordinate| the features can produce: |elevated_j| <= sum_i cf_i + j cf_j, cf_i = fmax_i * scale_i (Permutohedral::init)
@@ -621,13 +627,17 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     (void)hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
     // the spatial lattice depends on (H, W, sxy) only: built for ONE image, shared by the batch
     const int tw = (H % 16 == 0 && W % 16 == 0) ? (int)(W / 16) : 0;       // tile-major internal pixel order where the image tiles evenly
-    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s);
-    crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, tw, sxy_b, srgb, flags + 2, val0, val1, s);
+    // K(n) of each lattice - the filter of its norm, needed by the first update - is one more channel of the first iteration's filter
+    // (4 filter applications per lattice and call instead of 5) whenever the C candidate channels leave room for it
+    const bool ride = Ci + 1 <= CRF_MAXC;
+    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s, !ride);
+    crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, tw, sxy_b, srgb, flags + 2, val0, val1, s, !ride);
     const long nc = NT * Ci;
     hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci, (int)W, tw);
     for (int it = 0; it < iters; ++it) {
-        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, (int)B, s);
-        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, 1, s);
+        const bool first = ride && it == 0;
+        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, (int)B, s, first ? lat[0].kn : nullptr);
+        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, 1, s, first ? lat[1].kn : nullptr);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
                            q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci, (int)W, tw);

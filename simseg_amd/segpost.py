@@ -11,6 +11,8 @@ when the caller hands over the de-normalised network inputs (`images_u8`, what t
 map is the CRF's unary decision (prob > 0.5), and a caller-supplied `refine` hook can replace either.  Everything after it (7x7
 dilate + erode, nearest resize, score-weighted argmax, IoU histograms) is the reference's arithmetic again.
 """
+import os
+
 import torch
 
 from . import ops
@@ -19,7 +21,7 @@ from . import ops
 CRF_PARAMS = dict(sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3)        # tools/seg_evaluation.py:48-51
 
 
-def crf_masks(prob, cand_idx, images_u8, chunk=16, scale=1, **params):
+def crf_masks(prob, cand_idx, images_u8, chunk=None, scale=1, static=None, **params):
     """prob [B,K,h,w] fp32 normalised candidate maps (at 1/scale of the image resolution: the x16 nearest upsampling of the tool,
     tools/seg_evaluation.py:141-143, is applied here per chunk and only to visited slots), cand_idx [B,K] (-1 = slot not visited),
     images_u8 [B,H,W,3] -> uint8 masks [B,K,H,W] (0/255; unvisited slots zero).  One host read of the candidate table per batch (the
@@ -29,6 +31,19 @@ def crf_masks(prob, cand_idx, images_u8, chunk=16, scale=1, **params):
     B, K, h, w = prob.shape
     H, W = h * scale, w * scale
     dev = prob.device
+    if static is None:
+        static = os.environ.get("SIMSEG_CRF_STATIC", "0") != "0"
+    if static:
+        # Sync-free form (opt-in): no host read and no data-dependent shapes - every image goes through the CRF in ONE call with all K
+        # candidate slots as channels; slots the reference never visits carry the all-zero map seg_masks leaves there and their result is
+        # dropped.  K = 5 channels instead of the ~2 visited maps per image: measured 55.6 vs 28.4 ms per 63-window batch of 512^2
+        # (round 3), so the chunked form below stays the default.  (Replaying the CRF inside a hipGraph is NOT supported: a first
+        # attempt hung in replay - the hash build's probe loops never terminate if a table memset is not replayed - and was not pursued.)
+        up = prob if scale == 1 else prob.repeat_interleave(scale, 2).repeat_interleave(scale, 3)
+        m, _ = ops.dense_crf(images_u8.contiguous(), up.contiguous(), **dict(CRF_PARAMS, **params))
+        return m * (cand_idx >= 0).to(torch.uint8)[:, :, None, None]
+    if chunk is None:
+        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "16"))
     masks = torch.zeros(B, K, H, W, device=dev, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)

@@ -343,3 +343,24 @@ def test_segment_with_crf_matches_per_image_oracle_loop():
         agree.append((temp.argmax(0) == pred[b]).mean())
     print("prediction agreement with the oracle loop:", agree)
     assert min(agree) >= 0.998
+
+
+@pytest.mark.gpu
+def test_crf_static_form_equals_chunked():
+    """The sync-free CRF path (all candidate slots as channels, one call, no host read) gives the masks of the chunked path: an image's
+    lattices do not depend on which maps ride on them, and a map's mean field does not depend on the other channels."""
+    from simseg_amd import ops, segpost
+    B, n, C, H, W = 3, 6, 21, 96, 96
+    sim, scores, labels = _scene(5, B=B, n=n, C=C, H=H, W=W)
+    rng = np.random.default_rng(3)
+    imgs = rng.integers(0, 256, (B, 16 * n, 16 * n, 3), dtype=np.uint8)
+    imgs[:, : 8 * n] //= 4
+    sim, scores, imgs = sim.cuda(), scores.cuda(), torch.from_numpy(imgs).cuda()
+    cand_idx, _, _ = ops.seg_select(scores, 10, 5)
+    assert int((cand_idx >= 0).sum()) >= B
+    _, prob = ops.seg_masks(sim, cand_idx, n, want_prob=True)
+    p4 = prob.view(B, 5, n, n)
+    chunked = segpost.crf_masks(p4, cand_idx, imgs, scale=16, static=False)
+    static = segpost.crf_masks(p4, cand_idx, imgs, scale=16, static=True)
+    agree = float((chunked == static).float().mean())
+    assert agree >= 0.9995, agree                     # (fp32 sums in a different channel layout: a handful of boundary pixels at most)
