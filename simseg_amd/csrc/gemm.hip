@@ -1017,7 +1017,12 @@ __device__ __forceinline__ void pp_epilogue_f32_direct(const GemmParams& p, cons
 // PP_LEAD: half-tiles in flight ahead of the phase that reads them (3..5; the ring of two K-tiles allows up to 6).  PRIO: 1 = raise the
 // wave priority around every MFMA cluster, 2 = static priority for the second group only, 0 = none.  Measured (tools/gemm_bench.py,
 // r2): LEAD 3 / 4 / 5 and PRIO 0 / 1 / 2 are all within run-to-run noise (+-2 %) on the training shapes and on 4096^3 / 8192^3.
-template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1>
+// BIG = 1 (round 3 experiment, variant 14): TWO phases per K-tile instead of four - 16 MFMAs between a phase's barriers.  Phase X reads A
+// half 0 and both B halves (16 fragment reads), stages A half 1 of the next K-tile (2 copies) and multiplies A half 0 by both B halves;
+// phase Y reads A half 1 (8 reads), stages B half 0 / A half 0 / B half 1 of the K-tile after next (6 copies: those slots were last read
+// in phase X) and multiplies A half 1 by both B halves.  Every half-tile is requested two phases (one K-tile) before it is read;
+// vmcnt(8) in every phase.  Half as many barrier pairs per MFMA.
+template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1, int BIG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1090,6 +1095,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (p.dbg_trace) tr0 = wall_clock64();
+    if constexpr (BIG) {
+        PP_STAGE(0, 0) PP_STAGE(1, 1) PP_STAGE(2, 2) PP_STAGE(3, 3) PP_STAGE(4, 0) PP_STAGE(5, 1) PP_STAGE(6, 2)
+        wait_vm<8>();                                               // half-tiles 0..2 (what phase X of the first K-tile reads)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) __builtin_amdgcn_s_barrier();                 // the second group runs one barrier behind the first
+        if (p.dbg_trace) tr1 = wall_clock64();
+#define PP_BIGPHASE(READS, STAGES, RH, CA, FA_, CB, FB_)                                       \
+    {                                                                                          \
+        READS                                                                                  \
+        STAGES                                                                                 \
+        wait_vm<8>();                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        __builtin_amdgcn_s_barrier();                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        PP_CLUSTER(RH, CA, FA_)                                                                \
+        PP_CLUSTER(RH, CB, FB_)                                                                \
+        asm volatile("" : "+v"(acc[2 * (RH)][0]), "+v"(acc[2 * (RH) + 1][0]), "+v"(acc[2 * (RH)][1]), "+v"(acc[2 * (RH) + 1][1])); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        __builtin_amdgcn_s_barrier();                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+        for (int tt = 0; tt < ntile; ++tt) {
+            PP_BIGPHASE(PP_READ_B(fb0, 0, 0) PP_READ_A(0, 0) PP_READ_B(fb1, 0, 1), PP_STAGE(4 * tt + 7, 3), 0, 0, fb0, 1, fb1)
+            frb.toggle(2 * PP_HALF);
+            PP_BIGPHASE(PP_READ_A(0, 1), PP_STAGE(4 * tt + 8, 0) PP_STAGE(4 * tt + 9, 1) PP_STAGE(4 * tt + 10, 2), 1, 1, fb1, 0, fb0)
+            fra.toggle(2 * PP_HALF);
+        }
+#undef PP_BIGPHASE
+    } else {
     // ---- prologue: half-tiles 0..PP_LEAD on their way, 0 and 1 landed, B half 0 of the first K-tile in registers
     PP_STAGE(0, 0) PP_STAGE(1, 1) PP_STAGE(2, 2) PP_STAGE(3, 3)
     if (PP_LEAD >= 4) PP_STAGE(4, 0)
@@ -1133,6 +1169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         for (int kk = 0; kk < 4; ++kk) fb0[kk] = fb1[kk];
     }
 #undef PP_PHASE
+    }
 #undef PP_STAGE
 #undef PP_READ_A
 #undef PP_READ_B
@@ -1204,11 +1241,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1>
+template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1, int BIG = 0>
 int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
-    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO>;
+    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO, BIG>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
@@ -1635,7 +1672,8 @@ thread_local int g_gemm_variant = 0;
 template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
     const bool big_ok = aligned && p.K % 64 == 0 && p.M >= 256 && p.N >= 128;
-    int v = g_gemm_variant;
+    const bool four_phase = g_gemm_variant == 15;       // 15 = the automatic choice, ping-pong kernel on its four-phase schedule (A/B runs)
+    int v = four_phase ? 0 : g_gemm_variant;
     const int nk64 = p.K / 64;
     const int kper = (nk64 + (splitk > 1 ? splitk : 1) - 1) / (splitk > 1 ? splitk : 1);   // 64-deep slabs per block
     // measured (profiles/r1_gemm_variants.txt, after the epilogue was rolled to fit the instruction cache): the 256x256
@@ -1649,7 +1687,10 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         if ((v == 0 || v == 6 || v == 3) && v != 7 && big_ok && p.accumulate && splitk > 1 && p.M % 256 == 0 && p.N % 256 == 0 && tiles256 <= 128) {
             int sk = 256 / tiles256;
             if (nk64 / sk < 16 && nk64 >= 64) sk = nk64 / 16;        // short contraction (packed text rows): fewer, 16-deep slices
-            if (nk64 / sk >= 16 && tiles256 * sk >= 96 && (v == 3 || v == 0)) { g_gemm_last_variant = 3; return launch_pp<TO, TA, TB>(p, sk, s); }
+            if (nk64 / sk >= 16 && tiles256 * sk >= 96 && (v == 3 || v == 0)) {
+                g_gemm_last_variant = 3;
+                return four_phase ? launch_pp<TO, TA, TB>(p, sk, s) : launch_pp<TO, TA, TB, 4, 1, 1>(p, sk, s);
+            }
             if (nk64 / sk >= 16 && v == 6) { g_gemm_last_variant = 2; return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, sk, s); }
         }
         if (v == 3) v = 0;
@@ -1663,7 +1704,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // one round of 128x128 tiles (more than the small-problem kernel takes, at most a block per CU): the ring variant's three slabs in
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (v == 1 && g_gemm_variant == 0 && !TA && !TB && splitk <= 1 && t128 >= 160 && t128 <= 256) v = 5;
+    if (v == 1 && (g_gemm_variant == 0 || four_phase) && !TA && !TB && splitk <= 1 && t128 >= 160 && t128 <= 256) v = 5;
     if (v == 8 || v == 9) {      // experiments: 256x128 / 128x256 tiles, 4-wave blocks, two blocks per CU (one block's epilogue under the other's K loop)
         if (aligned && p.K % 32 == 0 && p.M >= 256 && p.N >= 256) {
             g_gemm_last_variant = v;
@@ -1687,7 +1728,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         // of LDS per CU: nothing co-resides), so the other tower's kernels - GEMM tiles, LayerNorm, attention - no longer slip into
         // the tails and memory-bound phases of this tower's; the per-tile kernel hands its CUs back after every tile.
         if constexpr (!TA) {
-            if (g_gemm_variant >= 10 && pp2_ok<TO>(p, splitk)) {
+            if (g_gemm_variant >= 10 && g_gemm_variant <= 13 && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
                 switch (g_gemm_variant) {           // 11..13: schedule experiments (see SCHED)
                     case 11: return launch_pp2<TO, TA, TB, 1>(p, s);
@@ -1698,6 +1739,8 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
             }
         }
         g_gemm_last_variant = 3;
+        // 16-MFMA phases (round 3) unless variant 15 asks for the four-phase schedule (A/B runs)
+        if (!four_phase && p.K >= 128) return launch_pp<TO, TA, TB, 4, 1, 1>(p, splitk, s);
         return launch_pp<TO, TA, TB>(p, splitk, s);
     }
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
@@ -1777,7 +1820,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     // measured (profiles/r2_gemm_small_problem.txt): ahead of the 128x128 kernel up to ~160 of its tiles in bf16, ~200 in fp32
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
     const bool small_auto = small_fit && t128 < (in_dtype == 0 ? 200 : 160);
-    if ((g_gemm_variant == 0 && small_auto) || (g_gemm_variant == 4 && small_fit)) {
+    if (((g_gemm_variant == 0 || g_gemm_variant == 15) && small_auto) || (g_gemm_variant == 4 && small_fit)) {
         g_gemm_last_variant = 4;
         if (in_dtype == 0) return dispatch_small<float, float>(p, s);
         return out_dtype ? dispatch_small<bf16_t, bf16_t>(p, s) : dispatch_small<bf16_t, float>(p, s);
