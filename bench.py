@@ -487,6 +487,7 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seg", action="store_true", help="skip the zero-shot-seg eval stage measurement")
+    ap.add_argument("--retrieval", action="store_true", help="with --no-seg: still run the (quick) retrieval metric legs")
     args = ap.parse_args()
 
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
@@ -530,7 +531,9 @@ def main():
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
         pg_info["ranks"] = ranks
-        assert len({r.get("pci", r["device"]) for r in ranks}) == world, f"two ranks share a device: {ranks}"
+        if len({r.get("pci", r["device"]) for r in ranks}) != world:
+            pg_info["warning"] = "two ranks report the same device"
+            log(f"WARNING: two ranks share a device: {ranks}")
     else:
         pg_info["ranks"] = [me]
     from simseg.models import PIPELINE
@@ -662,12 +665,14 @@ def main():
         if cpu_seg is not None:
             seg["cpu_baseline"] = cpu_seg
         log(f"seg eval stage: {seg}")
-    retr_multi = retrieval_multi_rank_bench(dev, rank, world) if (world > 1 and not args.no_seg) else None       # collective: every rank
-    retr = retrieval_bench(dev) if (rank == 0 and not args.no_seg) else None
+    want_retr = (not args.no_seg) or args.retrieval
+    retr_multi = retrieval_multi_rank_bench(dev, rank, world) if (world > 1 and want_retr) else None       # collective: every rank
+    retr = retrieval_bench(dev) if (rank == 0 and want_retr) else None
     if retr is not None and retr_multi is not None:
         retr["multi_rank"] = retr_multi
     if retr is not None:
-        retr["encoder_inclusive"] = retrieval_encode_bench(dev)
+        if not args.no_seg:
+            retr["encoder_inclusive"] = retrieval_encode_bench(dev)
         if cpu_retr is not None:
             retr["cpu_baseline"] = cpu_retr
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"

@@ -35,7 +35,7 @@ def make(kind, M, N, K, act):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="3,10")
+    ap.add_argument("--variants", default="15,0")
     ap.add_argument("--shapes", default="train")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=5)
