@@ -30,6 +30,8 @@ struct AttnParams {
     unsigned long long* trace;   // debugging (simseg_debug_attn_trace): per block {start, operands landed, end} wall-clock stamps
     int pack;           // resident kernels: rows past the last unmasked key of a sequence are neither read nor written (see attn_teff)
     float* colsum_ws;   // one-kernel backward: [B][3*H*64] per-sequence column sums of dqkv (the qkv bias gradient before the fold over B), or null
+    int pf_stride;      // one-kernel backward: > 0 = touch the operands of head blockIdx.x + pf_stride (the head that takes this CU's place in the
+                        // next round) during the tile loop, so that its copies find them in this XCD's L2; 0 = off
 };
 
 // online softmax update for one 64-key tile; s[kb][r] holds raw scores for key kb*32 + (r%4) + 8*(r/4) + 4*(lane/32)
@@ -1598,7 +1600,7 @@ constexpr int ONE_ST = 32 * ONE_TP;      // one staged tile
 
 __host__ __device__ inline int one_smem(int T) {
     const int q32 = (T + 31) / 32, rows32 = q32 * 32;
-    return 3 * rows32 * 128 + 2 * q32 * ONE_ST + 2 * rows32 * 4;
+    return 3 * rows32 * 128 + 2 * q32 * ONE_ST + 2 * rows32 * 4 + 8 * 256;      // (+ the landing pad of the next head's touches, 256 B per wave)
 }
 
 template <bool DROP>
@@ -1700,6 +1702,31 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     // arithmetic needs the 16 registers - spilled, a V fragment's scratch round trip sits in the prologue and in every step)
     __syncthreads();
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4 + 1] = wall_clock64();
+    // With one block per CU the dispatcher keeps the CUs in step: all load (an HBM burst, matrix cores idle: 6.4 of a block's 17.5 us at
+    // T = 197), all compute (HBM idle), all store.  The operands of THIS head are out of L2's way now (they sit in LDS / registers and are
+    // read once), so the head that will take this CU's place - blockIdx.x + pf_stride, same XCD - has its operands touched here: one lane
+    // per 128-byte row slice (a head's row of q, k, v, dO or O is exactly one cache line), 4 bytes each, landing in a 256-byte pad
+    // nobody reads.  ~1000 lines = 16-20 wave-instructions per head, spread over the tile loop's 9 us instead of the next block's prologue;
+    // issued from inline asm (the compiler's own wait counting never sees them: no vmcnt(0) in front of the step barriers).
+    if (p.pf_stride > 0 && bh_ + p.pf_stride < p.B * p.H) {
+        const int nh_ = bh_ + p.pf_stride;
+        const int nb_ = nh_ / p.H, nhh_ = nh_ % p.H;
+        const char* qb_ = reinterpret_cast<const char*>(p.qkv) + ((long)nb_ * Tf * RS + nhh_ * 64) * 2;
+        const char* gb_ = reinterpret_cast<const char*>(p.dout) + ((long)nb_ * Tf * OS + nhh_ * 64) * 2;
+        const char* ob_ = reinterpret_cast<const char*>(p.out) + ((long)nb_ * Tf * OS + nhh_ * 64) * 2;
+        // (rows32 comes out of shuffles / LDS in attn_teff: uniform, but not provably so - the M0 operand must be scalar)
+        const unsigned pad_ = __builtin_amdgcn_readfirstlane(
+            (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(del_l + rows32)) + wave * 256);
+        const int groups_ = (Tf + 63) >> 6;                                       // wave-instructions per operand
+        const int nparts_ = p.dbg == 5 ? 3 : (p.dbg == 6 ? 2 : (p.dbg == 7 ? 4 : 5));      // (A/B: how much of the head fits beside everything else in L2)
+        for (int k = wave; k < nparts_ * groups_; k += nw) {
+            const int part = k / groups_;
+            const int r = min((k - part * groups_) * 64 + lane, Tf - 1);
+            const char* sb_ = part < 3 ? qb_ + (long)part * (p.H * 128) : (part == 3 ? gb_ : ob_);
+            const unsigned voff = (unsigned)((long)r * (part < 3 ? RS : OS) * 2);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sb_), "s"(pad_) : "memory");
+        }
+    }
 #pragma unroll 1
     for (int j = 0; j < q32; ++j) {
         char* stj = stage + (j & 1) * nw * ONE_ST;
@@ -1891,7 +1918,16 @@ int launch_bwd_one(const AttnParams& p, hipStream_t stream) {
         configured = true;
     }
     const int q32 = (p.T + 31) / 32;
-    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)(p.B * p.H)), dim3(q32 * 64), one_smem(p.T), stream, p);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
+    }
+    AttnParams q = p;
+    // one block per CU is resident (LDS) for T > 128; shorter sequences fit two.  Variant 4 switches the next-head touches off (A/B runs).
+    const int per_cu = one_smem(p.T) > 80 * 1024 ? 1 : 2;
+    q.pf_stride = (cus > 0 && p.dbg != 4 && per_cu == 1 && (long)p.B * p.H > (long)cus) ? cus : 0;      // (two blocks per CU - T = 77 - measured 9 % slower with them)
+    hipLaunchKernelGGL(attn_bwd_one_kernel<DROP>, dim3((unsigned)(p.B * p.H)), dim3(q32 * 64), one_smem(p.T), stream, q);
     return 0;
 }
 

@@ -59,6 +59,7 @@ struct GemmParams {
     // dropout on (acc*alpha + bias), before the residual:  keep iff hash(seed, row*N+col) >= thresh
     unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the producing layer)
+    int pf_next;             // ping-pong kernel: the tail's copies fetch the next tile of this XCD (see gemm_pp_kernel)
 };
 
 template <typename T> struct TT;
@@ -1040,6 +1041,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     const char* Ab = static_cast<const char*>(p.A) + (TA ? (long)kt0 * 64 * p.lda * 2 : (long)kt0 * 128);
     const char* Bb = static_cast<const char*>(p.B) + (TB ? (long)kt0 * 64 * p.ldb * 2 : (long)kt0 * 128);
     const long astep = TA ? 64 * p.lda * 2 : 128, bstep = TB ? 64 * p.ldb * 2 : 128;
+    // The copies issued past the block's last K-tile (they keep the vmcnt arithmetic uniform) used to re-read the last K-tile into the
+    // dummy slot.  They now read what the NEXT block of this XCD will want first - the first seven half-tiles of the tile 32 places on
+    // in this XCD's run (one block per CU, 32 CUs per XCD: the tile that takes this round's place) - so that block's prologue finds its
+    // operands in this XCD's L2 / the Infinity Cache instead of HBM.  A per-lane offset belongs to this tile's rows; the next tile's
+    // rows are a scalar distance away as long as both tiles are full.  p.pf_next = 0 switches it off (A/B).
+    long dA = 0, dB = 0;
+    bool pf_ok = false;
+    if (BIG && p.pf_next && p.nsplit == 1) {
+        const int nb8 = (int)gridDim.x >> 3, rr8 = (int)gridDim.x & 7, xx = (int)blockIdx.x & 7, jj = (int)blockIdx.x >> 3;
+        if (jj + 32 < nb8 + (xx < rr8 ? 1 : 0)) {
+            const int tn_ = t + 32;                                  // (kz = 0: no split-K here)
+            const int m1 = (tn_ / tiles_n) * 256, n1 = (tn_ % tiles_n) * 256;
+            if (m0 + 256 <= p.M && n0 + 256 <= p.N && m1 + 256 <= p.M && n1 + 256 <= p.N) {
+                pf_ok = true;
+                dA = TA ? (long)(m1 - m0) * 2 : (long)(m1 - m0) * p.lda * 2;
+                dB = TB ? (long)(n1 - n0) * 2 : (long)(n1 - n0) * p.ldb * 2;
+            }
+        }
+    }
     unsigned offA[2][2], offB[2][2];                                 // [half][piece of this wave]
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1070,10 +1090,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     {                                                                                                                 \
         const int h_ = (H_);                                                                                          \
         const bool live_ = h_ < stot;                                                                                 \
-        const int kt_ = live_ ? (h_ >> 2) : ntile - 1;                                                                \
+        const int kt_ = live_ ? (h_ >> 2) : (pf_ok ? ((h_ - stot) >> 2) : ntile - 1);                                 \
         const unsigned dst_ = lds0 + (live_ ? (((KIND) & 1) ? 0 : PP_BREG) + (((h_ >> 2) & 1) * 2 + ((KIND) >> 1)) * PP_HALF : PP_DUMMY) + \
                               wave * 2048;                                                                            \
-        const char* sb_ = ((KIND) & 1) ? Ab + kt_ * astep : Bb + kt_ * bstep;                                         \
+        const char* sb_ = ((KIND) & 1) ? Ab + kt_ * astep + (live_ ? 0 : dA) : Bb + kt_ * bstep + (live_ ? 0 : dB);   \
         pp_glds16(((KIND) & 1) ? offA[(KIND) >> 1][0] : offB[(KIND) >> 1][0], sb_, dst_);                             \
         pp_glds16(((KIND) & 1) ? offA[(KIND) >> 1][1] : offB[(KIND) >> 1][1], sb_, dst_ + 1024);                      \
     }
@@ -1174,7 +1194,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_CLUSTER
-    wait_vm<0>();                                                    // (dummy copies of the tail)
+    // (the tail's copies land in the dummy slot, which no epilogue touches: when they fetch the next tile's operands - HBM latency -
+    //  they are waited for at the END of the epilogue, counted behind its stores, instead of here)
+    if (!pf_ok) wait_vm<0>();
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // both groups have left the last phase: the ring is free
     if (p.dbg_trace) tr2 = wall_clock64();
 
@@ -1195,6 +1217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
             pp_epilogue_bf16(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
+            if (pf_ok) wait_vm<16>();                                // >= 16 stores were issued after the tail's copies: those have landed
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1214,6 +1237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                             !p.dbg_skip_epilogue && m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (direct) {
             pp_epilogue_f32_direct(p, acc, m0, c0, c1, grp, lane);
+            if (pf_ok) wait_vm<63>();                                // 128 stores behind the tail's copies
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1233,6 +1257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         epilogue_block<TO>(p, l, r, wlds, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32, c0, c1, lane, atomic, vec_ok, cs);
     }
     flush_colsum(p, cs, c0, c1, lane);
+    if (pf_ok) wait_vm<0>();
     if (p.dbg_trace && tid == 0) {
         const unsigned long long tr3 = wall_clock64();               // every store of this wave is issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... and acknowledged
@@ -1673,7 +1698,7 @@ template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
     const bool big_ok = aligned && p.K % 64 == 0 && p.M >= 256 && p.N >= 128;
     const bool four_phase = g_gemm_variant == 15;       // 15 = the automatic choice, ping-pong kernel on its four-phase schedule (A/B runs)
-    int v = four_phase ? 0 : g_gemm_variant;
+    int v = (four_phase || g_gemm_variant == 16) ? 0 : g_gemm_variant;
     const int nk64 = p.K / 64;
     const int kper = (nk64 + (splitk > 1 ? splitk : 1) - 1) / (splitk > 1 ? splitk : 1);   // 64-deep slabs per block
     // measured (profiles/r1_gemm_variants.txt, after the epilogue was rolled to fit the instruction cache): the 256x256
@@ -1704,7 +1729,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     // one round of 128x128 tiles (more than the small-problem kernel takes, at most a block per CU): the ring variant's three slabs in
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (v == 1 && (g_gemm_variant == 0 || four_phase) && !TA && !TB && splitk <= 1 && t128 >= 160 && t128 <= 256) v = 5;
+    if (v == 1 && (g_gemm_variant == 0 || g_gemm_variant >= 15) && !TA && !TB && splitk <= 1 && t128 >= 160 && t128 <= 256) v = 5;
     if (v == 8 || v == 9) {      // experiments: 256x128 / 128x256 tiles, 4-wave blocks, two blocks per CU (one block's epilogue under the other's K loop)
         if (aligned && p.K % 32 == 0 && p.M >= 256 && p.N >= 256) {
             g_gemm_last_variant = v;
@@ -1813,6 +1838,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    p.pf_next = g_gemm_variant != 16;                                // 16 = automatic choice without the next-tile fetch (A/B runs)
     hipStream_t s = (hipStream_t)stream;
     g_gemm_last_variant = 1;
     // 0 auto, 4 = the small-problem kernel wherever it applies (tests), any other value keeps it off
@@ -1820,7 +1846,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     // measured (profiles/r2_gemm_small_problem.txt): ahead of the 128x128 kernel up to ~160 of its tiles in bf16, ~200 in fp32
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
     const bool small_auto = small_fit && t128 < (in_dtype == 0 ? 200 : 160);
-    if (((g_gemm_variant == 0 || g_gemm_variant == 15) && small_auto) || (g_gemm_variant == 4 && small_fit)) {
+    if (((g_gemm_variant == 0 || g_gemm_variant >= 15) && small_auto) || (g_gemm_variant == 4 && small_fit)) {
         g_gemm_last_variant = 4;
         if (in_dtype == 0) return dispatch_small<float, float>(p, s);
         return out_dtype ? dispatch_small<bf16_t, bf16_t>(p, s) : dispatch_small<bf16_t, float>(p, s);
