@@ -130,6 +130,18 @@ int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* o
                          float* workspace, void* dqkv, float* dqkv_colsum, int dtype, int64_t B, int64_t T, int64_t H, float scale,
                          uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
 
+/* The same attention for a ragged batch stored WITHOUT its padding (bf16, at most T <= 256 tokens per sequence): sequence b is rows
+ * [row_start[b], row_start[b+1]) of qkv [rows,3,H,64] / out, dout [rows,H*64] / dqkv (row_start: B+1 ascending int32 on the device),
+ * every stored token is real.  Attention has no notion of position, so this IS HF BertSelfAttention with its key-padding mask
+ * (huggingface_builder.py:16-17) evaluated on the unmasked tokens; the rows a padded layout would carry are never formed.  lse
+ * [B,H,T] (log2 domain).  Rows outside every sequence (a caller's tile padding) are not touched.  workspace / dqkv_colsum as in
+ * simseg_attention_bwd. */
+int simseg_attention_fwd_rows(const void* qkv, const int32_t* row_start, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale,
+                              uint64_t drop_seed, float drop_p, void* stream);
+int simseg_attention_bwd_rows(const void* qkv, const int32_t* row_start, const void* out, const void* dout, const float* lse,
+                              float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
+                              float drop_p, void* stream);
+
 /* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).
  * tools/seg_evaluation.py:71-73 (class_embeddings.mean(dim=0); /= norm()). */
 int simseg_segment_mean_l2norm(const float* x, float* out, int64_t S, int64_t P, int64_t D, void* stream);

@@ -30,6 +30,8 @@ struct AttnParams {
     unsigned long long* trace;   // debugging (simseg_debug_attn_trace): per block {start, operands landed, end} wall-clock stamps
     int pack;           // resident kernels: rows past the last unmasked key of a sequence are neither read nor written (see attn_teff)
     float* colsum_ws;   // one-kernel backward: [B][3*H*64] per-sequence column sums of dqkv (the qkv bias gradient before the fold over B), or null
+    const int* row_start;   // resident forward / one-kernel backward: ragged batch stored WITHOUT its padding - sequence b occupies rows
+                            // [row_start[b], row_start[b+1]) of qkv / out / dout / dqkv, every stored token is real; null = dense [B, T] rows
     int pf_stride;      // one-kernel backward: > 0 = touch the operands of head blockIdx.x + pf_stride (the head that takes this CU's place in the
                         // next round) during the tile loop, so that its copies find them in this XCD's L2; 0 = off
 };
@@ -730,6 +732,7 @@ __device__ __forceinline__ int res_rows8(int T) { return (T + 7) & ~7; }
 // caller neither reads the outputs nor uses the gradients of the query rows past it, so the kernels treat the sequence as T_eff long:
 // fewer rows copied, fewer tiles.  Block-uniform; p.T when the flag is off, there is no mask, or every key is masked.
 __device__ __forceinline__ int attn_teff(const AttnParams& p, int b) {
+    if (p.row_start) return p.row_start[b + 1] - p.row_start[b];
     if (!p.pack || !p.mask) return p.T;
     __shared__ int sh_last[4];
     int last = -1;
@@ -750,9 +753,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
-    const int Tf = p.T, T = MASK ? attn_teff(p, b) : p.T;     // Tf: the tensors' row count; T: the rows this block works on
+    const int Tf = p.T, T = (MASK || p.row_start) ? attn_teff(p, b) : p.T;     // Tf: the dense row count per sequence; T: the rows this block works on
+    if (T <= 0) return;                                        // (an empty sequence of a ragged batch; uniform per block)
+    const long row0 = p.row_start ? (long)p.row_start[b] : (long)b * Tf;      // first row of this sequence in qkv / out
     const long RS = 3L * p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * 64;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int HD = p.H * 64;
     const int nt = (T + KT - 1) / KT, q32 = (T + 31) / 32;
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float ltot = lsum + __shfl_xor(lsum, 32, 64);
         const float inv = 1.0f / ltot;
         if (q < T) {
-            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * Tf + q) * p.H * 64 + h * 64;
+            bf16_t* orow = static_cast<bf16_t*>(p.out) + (row0 + q) * p.H * 64 + h * 64;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1620,11 +1625,17 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     const int bh_ = blockIdx.x;
     const int b = bh_ / p.H, h = bh_ % p.H;
     const int T = attn_teff(p, b);                    // the rows this block works on
+    if (T <= 0) {                                     // an empty sequence of a ragged batch: no rows, zero column sums (uniform per block)
+        if (p.colsum_ws)
+            for (int i = tid; i < 192; i += nthr) p.colsum_ws[((long)b * 3 + i / 64) * (p.H * 64) + h * 64 + (i & 63)] = 0.f;
+        return;
+    }
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4] = wall_clock64();
     const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * Tf * RS + h * 64;
-    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + (long)b * Tf * OS + h * 64;
-    const bf16_t* obase = static_cast<const bf16_t*>(p.out) + (long)b * Tf * OS + h * 64;
+    const long row0 = p.row_start ? (long)p.row_start[b] : (long)b * Tf;      // first row of this sequence in qkv / out / dout / dqkv
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * 64;
+    const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + row0 * OS + h * 64;
+    const bf16_t* obase = static_cast<const bf16_t*>(p.out) + row0 * OS + h * 64;
     const int q32 = (T + 31) / 32, rows32 = q32 * 32;
     char* ldsQ = lds;
     char* ldsG = lds + rows32 * 128;
@@ -1711,9 +1722,10 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     if (p.pf_stride > 0 && bh_ + p.pf_stride < p.B * p.H) {
         const int nh_ = bh_ + p.pf_stride;
         const int nb_ = nh_ / p.H, nhh_ = nh_ % p.H;
-        const char* qb_ = reinterpret_cast<const char*>(p.qkv) + ((long)nb_ * Tf * RS + nhh_ * 64) * 2;
-        const char* gb_ = reinterpret_cast<const char*>(p.dout) + ((long)nb_ * Tf * OS + nhh_ * 64) * 2;
-        const char* ob_ = reinterpret_cast<const char*>(p.out) + ((long)nb_ * Tf * OS + nhh_ * 64) * 2;
+        const long nr_ = p.row_start ? (long)p.row_start[nb_] : (long)nb_ * Tf;
+        const char* qb_ = reinterpret_cast<const char*>(p.qkv) + (nr_ * RS + nhh_ * 64) * 2;
+        const char* gb_ = reinterpret_cast<const char*>(p.dout) + (nr_ * OS + nhh_ * 64) * 2;
+        const char* ob_ = reinterpret_cast<const char*>(p.out) + (nr_ * OS + nhh_ * 64) * 2;
         // (rows32 comes out of shuffles / LDS in attn_teff: uniform, but not provably so - the M0 operand must be scalar)
         const unsigned pad_ = __builtin_amdgcn_readfirstlane(
             (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(del_l + rows32)) + wave * 256);
@@ -1853,7 +1865,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     if (active) {
         constexpr int OP = 144;                       // bytes per staged row (128 + 16: 16-byte aligned rows)
         char* ob = stage + wave * (2 * ONE_ST);       // 32 x 144 = 4 608 B
-        bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + (long)b * Tf * RS + h * 64 + (long)(wave * 32) * RS;
+        bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + row0 * RS + h * 64 + (long)(wave * 32) * RS;
         float* cpart = reinterpret_cast<float*>(ldsQ);                 // [wave][3][64] column sums (the operand images are free by now)
         auto put = [&](const f32x16 (&acc)[2], int sel, float mul) {
 #pragma unroll
@@ -2103,5 +2115,40 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
     }
     SS_LAUNCH_CHECK("attention_bwd");
     if (dqkv_colsum) return simseg_colsum_accum(dqkv, 1, dqkv_colsum, B * T, 3 * H * 64, 3 * H * 64, stream);
+    return 0;
+}
+
+// ---- ragged batches stored without their padding (the packed text tower) -------------------------------------------------------
+// qkv [rows, 3, H, 64], out / dout [rows, H*64], dqkv like qkv: sequence b is rows [row_start[b], row_start[b+1]) (row_start: B + 1
+// int32 on the device, ascending), at most T tokens (T <= 256), every stored token real - attention has no notion of position, so
+// this is the masked dense computation on the unmasked tokens (HF BertSelfAttention with a key-padding mask; the reference's captions
+// are prefix-masked).  lse [B, H, T].  The dropout hash is indexed by (sequence, head, query index, key index) with stride T as in the
+// dense entry points: for prefix masks the same probabilities are dropped.  bf16 only.
+extern "C" int simseg_attention_fwd_rows(const void* qkv, const int32_t* row_start, void* out, float* lse, int64_t B, int64_t T, int64_t H,
+                                         float scale, uint64_t drop_seed, float drop_p, void* stream) {
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out && row_start, "attention_fwd_rows: null pointer");
+    SS_CHECK(T <= RES_MAXT, "attention_fwd_rows: sequences of at most %d tokens (got %lld)", RES_MAXT, (long long)T);
+    p.out = out; p.lse = lse; p.row_start = row_start;
+    int rc = p.drop_thresh ? launch_fwd_res<true, true>(p, (hipStream_t)stream) : launch_fwd_res<false, false>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    SS_LAUNCH_CHECK("attention_fwd_rows");
+    return 0;
+}
+
+extern "C" int simseg_attention_bwd_rows(const void* qkv, const int32_t* row_start, const void* out, const void* dout, const float* lse,
+                                         float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H, float scale,
+                                         uint64_t drop_seed, float drop_p, void* stream) {
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out && dout && lse && workspace && dqkv && row_start, "attention_bwd_rows: null pointer");
+    SS_CHECK(T <= ONE_MAXT, "attention_bwd_rows: sequences of at most %d tokens (got %lld)", ONE_MAXT, (long long)T);
+    p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = workspace; p.dqkv = dqkv; p.row_start = row_start;
+    hipStream_t s = (hipStream_t)stream;
+    p.colsum_ws = dqkv_colsum ? workspace + B * H * T : nullptr;
+    if (int rc = p.drop_thresh ? launch_bwd_one<true>(p, s) : launch_bwd_one<false>(p, s)) return rc;
+    SS_LAUNCH_CHECK("attention_bwd_rows");
+    if (dqkv_colsum) return simseg_colsum_accum(p.colsum_ws, 0, dqkv_colsum, B, 3 * H * 64, 3 * H * 64, stream);
     return 0;
 }

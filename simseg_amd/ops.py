@@ -205,6 +205,38 @@ def attention_bwd(qkv, out, dout, lse, heads, mask=None, scale=0.125, drop_seed=
     return dqkv
 
 
+def attention_fwd_rows(qkv, heads, row_start, max_len, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0, n_real=None):
+    """Ragged batch without padding: qkv [rows, 3*H*64] bf16, sequence b = rows [row_start[b], row_start[b+1]) (int32 [B+1]), at most
+    max_len tokens each -> ctx [rows, H*64] (rows outside every sequence - a tile padding behind row n_real - are zeros), lse [B,H,max_len]."""
+    require_gpu(qkv, row_start)
+    if qkv.dtype != torch.bfloat16 or row_start.dtype != torch.int32:
+        raise TypeError("attention_fwd_rows: bf16 qkv, int32 row_start")
+    rows, W = qkv.shape
+    B = row_start.numel() - 1
+    out = torch.empty(rows, heads * 64, device=qkv.device, dtype=qkv.dtype)
+    if n_real is not None and n_real < rows:
+        out[n_real:].zero_()
+    lse = torch.empty(B, heads, max_len, device=qkv.device, dtype=torch.float32) if save_lse else None
+    _push_variant("attention")
+    call("simseg_attention_fwd_rows", ptr(_c(qkv)), ptr(_c(row_start)), ptr(out), ptr(lse), B, int(max_len), heads, float(scale), int(drop_seed),
+         float(drop_p), stream())
+    return out, lse
+
+
+def attention_bwd_rows(qkv, out, dout, lse, heads, row_start, max_len, scale=0.125, drop_seed=0, drop_p=0.0, colsum=None, n_real=None):
+    """dqkv [rows, 3*H*64] for attention_fwd_rows (rows behind n_real zeroed); colsum (optional fp32 [3*H*64]) += its column sums."""
+    rows, W = qkv.shape
+    B = row_start.numel() - 1
+    dqkv = torch.empty_like(qkv)
+    if n_real is not None and n_real < rows:
+        dqkv[n_real:].zero_()
+    ws = torch.empty(raw("simseg_attention_bwd_workspace_bytes", B, int(max_len), heads) // 4, device=qkv.device, dtype=torch.float32)
+    _push_variant("attention")
+    call("simseg_attention_bwd_rows", ptr(_c(qkv)), ptr(_c(row_start)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(ws), ptr(dqkv), ptr(colsum),
+         B, int(max_len), heads, float(scale), int(drop_seed), float(drop_p), stream())
+    return dqkv
+
+
 def segment_mean_l2norm(x):
     """[S,P,D] fp32 -> [S,D]: unit-norm mean over P."""
     require_gpu(x)

@@ -426,11 +426,38 @@ def ragged_maps(mask, multiple=256):
     return idx, inv, nv
 
 
+def ragged_rows(mask):
+    """int32 [B+1] first packed row of every sequence (the packed order of ragged_maps keeps a sequence's real tokens together), or None
+    when some mask has a hole - a real token behind a masked one.  The attention kernels then take the packed rows directly
+    (simseg_attention_fwd_rows): no round trip through the dense [B, L] layout.  For prefix masks - every caption the reference's
+    tokenizer produces - a token's index inside its packed sequence equals its position, so the dropout hash drops the same
+    probabilities as the dense path; with holes the packed path would still be the same function but not the same random mask, so the
+    dense path stays.  One more host read per mask tensor (cached on it like the maps)."""
+    cached = getattr(mask, "_simseg_rows", None)
+    if cached is not None and cached[0] == mask._version:
+        return cached[1]
+    real = mask != 0
+    lens = real.sum(1)
+    holes = (real & (torch.arange(mask.shape[1], device=mask.device)[None] >= lens[:, None])).any()
+    cu = torch.zeros(mask.shape[0] + 1, device=mask.device, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    out = None if bool(holes) else cu
+    try:
+        mask._simseg_rows = (mask._version, out)
+    except Exception:       # noqa: BLE001
+        pass
+    return out
+
+
+_PACKED_ATTN = os.environ.get("SIMSEG_AMD_PACKED_ATTN", "1") != "0"      # (A/B switch: attention on the packed rows)
+
+
 class BertLayerFn(Function):
     """HF BertLayer (post-LN, eps 1e-12): a = LN(x + drop(dense(attn(x)))); y = LN(a + drop(dense(gelu(dense(a)))))."""
 
     @staticmethod
-    def forward(ctx, x, mask, heads, adt, drop_p, seed, qw, qb, kw, kb, vw, vb, ow, ob, law, lab, iw, ib, o2w, o2b, low, lob, idx=None, inv=None):
+    def forward(ctx, x, mask, heads, adt, drop_p, seed, qw, qb, kw, kb, vw, vb, ow, ob, law, lab, iw, ib, o2w, o2b, low, lob, idx=None, inv=None,
+                cu=None, nv=0):
         # idx / inv given: x is [Nv, D], the real tokens of the ragged batch only (padded rows dropped).  Every GEMM, LayerNorm and
         # dropout then runs on Nv rows; only the attention kernels see the dense [B, L] layout (rows put back with zeros at the padded
         # positions: masked keys, and queries whose outputs are never read).
@@ -446,13 +473,18 @@ class BertLayerFn(Function):
             bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
         ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
         qkv = ops.gemm(xa, wqkv, bias=bqkv)
-        if packed:
-            qkv = ops.gather_rows(qkv, inv)                          # [B*L, 3D], zero rows at the padded positions
-        att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p,
-                                      skip_padded_rows=packed and _SKIP_PAD, zero_skipped=False)      # (only real rows are gathered below)
-        attd = att
-        if packed:
-            att = ops.gather_rows(att.view(-1, D), idx)              # [Nv, D]
+        rows = packed and cu is not None and adt == BF16             # attention straight on the packed rows
+        if rows:
+            att, lse = ops.attention_fwd_rows(qkv, heads, cu, L, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p, n_real=nv)
+            attd = None
+        else:
+            if packed:
+                qkv = ops.gather_rows(qkv, inv)                      # [B*L, 3D], zero rows at the padded positions
+            att, lse = ops.attention_fwd(qkv.view(B, L, 3 * D), heads, mask, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p,
+                                          skip_padded_rows=packed and _SKIP_PAD, zero_skipped=False)      # (only real rows are gathered below)
+            attd = att
+            if packed:
+                att = ops.gather_rows(att.view(-1, D), idx)          # [Nv, D]
         s1 = ops.gemm(att.view(-1, D), ow_, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
         aa = a32 if adt == F32 else a16
@@ -460,15 +492,15 @@ class BertLayerFn(Function):
         act = ops.gemm(aa, iw_, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, _, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, save_stats=save)
-        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed = adt, heads, (B, L, D), (drop_p, seed), packed
+        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
-                                  law.detach(), low.detach(), attd if packed else None, idx, inv)
+                                  law.detach(), low.detach(), attd if (packed and not rows) else None, idx, inv, cu if rows else None)
         return y if packed else y.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
-        (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low, attd, idx, inv) = ctx.saved_tensors
+        (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low, attd, idx, inv, cu) = ctx.saved_tensors
         B, L, D = ctx.dims
         packed = ctx.packed
         adt = ctx.adt
@@ -490,16 +522,20 @@ class BertLayerFn(Function):
                              drop=(p, seed + 1))
         datt = _dgrad(d1, ow_)
         dow = _wgrad(d1, att.view(-1, D), dow_z) if need[12] else None
-        if packed:
-            datt = ops.gather_rows(datt, inv)                        # back to [B*L, D] (zero rows at the padded positions)
         dbqkv = _zeros_like_bias(dbqkv_z, 3 * D, qkv.device) if (need[7] or need[9] or need[11]) else None
-        # (packed: rows of padded tokens carry no gradient - their dout is zero, their keys are masked - so the sums over the dense rows
-        # the kernel works on equal the sums over the packed rows)
-        dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
-                                 scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD,
-                                 colsum=dbqkv if _FUSED_QKV_BIAS else None, zero_skipped=False).view(-1, 3 * D)
-        if packed:
-            dqkv = ops.gather_rows(dqkv, idx)                        # [Nv, 3D]
+        if ctx.rows:                                                 # attention backward straight on the packed rows
+            dqkv = ops.attention_bwd_rows(qkv, att, datt.contiguous(), lse, ctx.heads, cu, L, scale=64 ** -0.5, drop_seed=seed, drop_p=p,
+                                          colsum=dbqkv if _FUSED_QKV_BIAS else None, n_real=ctx.nv)
+        else:
+            if packed:
+                datt = ops.gather_rows(datt, inv)                    # back to [B*L, D] (zero rows at the padded positions)
+            # (packed: rows of padded tokens carry no gradient - their dout is zero, their keys are masked - so the sums over the dense rows
+            # the kernel works on equal the sums over the packed rows)
+            dqkv = ops.attention_bwd(qkv.view(B, L, 3 * D), (attd if packed else att).view(B, L, D), datt.view(B, L, D), lse, ctx.heads, mask,
+                                     scale=64 ** -0.5, drop_seed=seed, drop_p=p, skip_padded_rows=packed and _SKIP_PAD,
+                                     colsum=dbqkv if _FUSED_QKV_BIAS else None, zero_skipped=False).view(-1, 3 * D)
+            if packed:
+                dqkv = ops.gather_rows(dqkv, idx)                    # [Nv, 3D]
         if dbqkv is not None and not _FUSED_QKV_BIAS:
             ops.colsum_accum(dqkv, dbqkv)
         dx = _dgrad(dqkv, wqkv, residual=ds1_32, out_dtype=F32)
@@ -507,7 +543,7 @@ class BertLayerFn(Function):
         dws = [dwqkv[i * D:(i + 1) * D] if dwqkv is not None else None for i in range(3)]
         dbs = [dbqkv[i * D:(i + 1) * D] if dbqkv is not None else None for i in range(3)]
         return (dx if packed else dx.view(B, L, D), None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dow, dob,
-                dlaw, dlab, diw, dib, do2w, do2b, dlow, dlob, None, None)
+                dlaw, dlab, diw, dib, do2w, do2b, dlow, dlob, None, None, None, None)
 
 
 # Ragged caption batches.  HF's BertModel computes every padded token (huggingface_builder.py:16-17); nothing downstream of the CLIP
@@ -541,13 +577,16 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     x = BertEmbedFn.apply(input_ids, mask, e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
                           e.LayerNorm.weight, e.LayerNorm.bias, p_h, seed)
     B, L, D = x.shape
-    idx = inv = None
+    idx = inv = cu = None
+    nv = 0
     if _PACK_TEXT[0] and x.is_cuda:
         idx, inv, nv = ragged_maps(mask)
         if nv == 0 or idx.numel() >= B * L:
             idx = inv = None                                        # nothing to drop
         else:
             x = RowMapFn.apply(x.view(-1, D), idx, inv)             # [Nv, D]
+            if _PACKED_ATTN and adt == BF16 and L <= 256:
+                cu = ragged_rows(mask)                              # None: a mask with a hole - attention through the dense layout
     for i, lyr in enumerate(m.encoder.layer):
         a, s = lyr.attention, lyr.attention.self
         x = BertLayerFn.apply(x, mask, m.num_heads, adt, p_h, seed + 16 * (i + 1),
@@ -555,7 +594,7 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
                               a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
                               lyr.intermediate.dense.weight, lyr.intermediate.dense.bias,
                               lyr.output.dense.weight, lyr.output.dense.bias, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias,
-                              idx, inv)
+                              idx, inv, cu, nv)
     if idx is not None:
         x = RowMapFn.apply(x, inv, idx).view(B, L, D)               # zeros at the padded positions
     return x

@@ -616,6 +616,52 @@ def test_attention_skip_padded_rows(ops, T):
             assert not out_s[b, n:].any() and not g_s[b, n:].any() and not lse_s[b, :, n:].any(), (T, b, p)
 
 
+@pytest.mark.parametrize("T", [25, 77, 200])
+def test_attention_on_packed_rows_equals_dense(ops, T):
+    """simseg_attention_fwd_rows / _bwd_rows: the ragged batch stored without its padding (sequence b = rows [row_start[b], row_start[b+1]))
+    against the dense, prefix-masked call with skip_padded_rows: forward output, log-sum-exp, every gradient row and the q/k/v bias
+    gradient agree to bf16 rounding, with and without dropout (the same dropout mask: the hash is indexed by sequence / query / key); lengths cover one token, tile edges, the full
+    length and an EMPTY sequence; rows behind the last sequence (a caller's tile padding) come back as zeros."""
+    B, H = 7, 2
+    lens = [T, 1, min(9, T), min(32, T), min(33, T), 0, T - 1]
+    mask = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    mask = mask.cuda()
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.2, dtype=torch.bfloat16)
+    dout = _rand(B, T, H * 64, seed=T + 1, dtype=torch.bfloat16)
+    idx = mask.view(-1).nonzero().flatten()
+    nv = idx.numel()
+    pad = 5
+    qp = torch.cat([qkv.view(B * T, -1)[idx], torch.full((pad, 3 * H * 64), float("nan"), device="cuda", dtype=torch.bfloat16)])
+    dp = torch.cat([dout.view(B * T, -1)[idx], torch.zeros(pad, H * 64, device="cuda", dtype=torch.bfloat16)])
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.tensor(lens).cumsum(0)
+    cu = cu.cuda()
+    for p, seed in ((0.0, 0), (0.1, 99)):
+        # the empty sequence: the dense call treats a fully masked sequence as unmasked - leave it out of the comparison
+        out_d, lse_d = ops.attention_fwd(qkv, H, mask, save_lse=True, drop_seed=seed, drop_p=p, skip_padded_rows=True)
+        cs_d = torch.zeros(3 * H * 64, device="cuda")
+        dmask = dout.clone()
+        dmask[5] = 0                                   # (its gradient rows do not exist in the packed layout)
+        for b, n in enumerate(lens):
+            dmask[b, n:] = 0
+        g_d = ops.attention_bwd(qkv, out_d, dmask, lse_d, H, mask, drop_seed=seed, drop_p=p, skip_padded_rows=True)
+        out_r, lse_r = ops.attention_fwd_rows(qp, H, cu, T, save_lse=True, drop_seed=seed, drop_p=p, n_real=nv)
+        cs_r = torch.zeros(3 * H * 64, device="cuda")
+        g_r = ops.attention_bwd_rows(qp, out_r, dp, lse_r, H, cu, T, drop_seed=seed, drop_p=p, colsum=cs_r, n_real=nv)
+        assert not out_r[nv:].any() and not g_r[nv:].any()
+        # (the unmasked forward instantiation tracks its running maximum over the real keys only, the masked one over the raw scores of
+        #  a whole tile: the same function, roundings one bf16 ulp apart)
+        _close(out_r[:nv], out_d.view(B * T, -1)[idx], 1e-2, f"packed rows forward T={T} p={p}")
+        _close(g_r[:nv], g_d.view(B * T, -1)[idx], 1.5e-2, f"packed rows backward T={T} p={p}")
+        for b, n in enumerate(lens):
+            if n:
+                _close(lse_r[b, :, :n], lse_d[b, :, :n], 1e-5, f"packed rows lse T={T} b={b} p={p}")
+        want_cs = g_d.view(B * T, -1)[idx].float().sum(0)
+        _close(cs_r, want_cs, 2e-3, f"qkv bias gradient from the packed rows T={T} p={p}")
+
+
 @pytest.mark.parametrize("T", [77, 197, 600])
 def test_attention_deferred_rescale_branch(ops, T):
     """The online softmax raises its running maximum (and rescales O, l) only when a tile's maximum exceeds it by more than a
