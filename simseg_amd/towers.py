@@ -466,7 +466,12 @@ class BertLayerFn(Function):
         D = x.shape[-1]
         x = x.contiguous()
         save = any(ctx.needs_input_grad)
-        xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
+        # (bf16: the previous layer's output LayerNorm has written a bf16 copy of x next to the fp32 rows - no cast pass)
+        sh16 = getattr(x, "_simseg_fwd16", None) if adt == BF16 else None
+        if sh16 is not None and sh16[1] == x._version and sh16[0].numel() == x.numel():
+            xa = sh16[0].view(-1, D)
+        else:
+            xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
         wqkv = _wt_stacked((qw, kw, vw), adt)                              # HF keeps three matrices; one fused [3D, D] GEMM here
         bqkv = _as_one(qb.detach(), kb.detach(), vb.detach())
         if bqkv is None:
@@ -491,7 +496,9 @@ class BertLayerFn(Function):
         pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
         act = ops.gemm(aa, iw_, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
-        y, _, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, save_stats=save)
+        y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt == BF16 and packed), save_stats=save)
+        if y16 is not None:
+            y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
         ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
