@@ -308,63 +308,73 @@ __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ 
     if (m < *M) start[m] = base + incl - n;
 }
 __global__ __launch_bounds__(256) void crf_fill_kernel(const int* __restrict__ off, const float* __restrict__ bary, const int* __restrict__ start,
-                                                       const int* __restrict__ rank, int* __restrict__ ent, float* __restrict__ entw, long nv, int d1) {
+                                                       const int* __restrict__ rank, int2* __restrict__ rec, long nv, int d1) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= nv) return;
     const int m = off[e];
     const int slot = start[m] + rank[e];
-    ent[slot] = (int)(e / d1);                                    // the pixel; its barycentric weight rides along (sequential reads later)
-    entw[slot] = bary[e];
+    rec[slot] = make_int2((int)(e / d1), __float_as_int(bary[e]));     // {pixel, barycentric weight}: ONE 8-byte record per entry
 }
-// val[(m + 1) * C + c] = sum over the entries e of point m of bary[e] * scale[pixel] * in[pixel * C + c]   (pixel = e / (D + 1))
+// val[(m + 1) * CS + c] = sum over the entries e of point m of w_e * in[pixel_e * CS + c]      (w_e already times scale[pixel] in `recs`)
 // G lanes per lattice point walk its list together (a point of the bilateral lattice has ~10-25 entries, of the spatial one more): the
 // list reads are contiguous per group instead of one cache line per lane, and the partial sums meet in a shuffle tree.
-template <int D>
-__global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict__ in, const float* __restrict__ scale, const int* __restrict__ start,
-                                                         const int* __restrict__ cnt, const int* __restrict__ ent, const float* __restrict__ entw,
-                                                         float* __restrict__ val, const int* __restrict__ M, int C, long in_stride, long val_stride,
-                                                         int extra) {
-    // extra = 1: one more channel behind the C channels of `in`, whose input is the constant 1 (times the entry weight): the filter of
-    // the lattice's norm rides along with the first mean-field filter instead of being a filter application of its own
+// CS = channel stride of every per-pixel / per-point array of the solver (4 for up to 4 channels, else 8): an entry costs one 8-byte
+// record load and one (two) 16-byte value load(s) instead of 2 + C scalar loads - the scattered reads are sector-sized either way.
+template <int D, int CS>
+__global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict__ in, const int* __restrict__ start, const int* __restrict__ cnt,
+                                                         const int2* __restrict__ rec, float* __restrict__ val, const int* __restrict__ M, int C,
+                                                         long in_stride, long val_stride, int extra) {
+    // extra = 1: channel C (behind the C channels of `in`) has the constant input 1 (times the entry weight): the filter of the lattice's
+    // norm rides along with the first mean-field filter instead of being a filter application of its own
     constexpr int G = D == 2 ? 16 : 8;
-    const int CT = C + extra;
     const int sub = threadIdx.x & (G - 1);
     if (in) in += (long)blockIdx.y * in_stride;                   // blockIdx.y: images that SHARE this lattice (the spatial one), see crf_filter
     val += (long)blockIdx.y * val_stride;
     const long Mr = ((long)*M + 256 / G - 1) / (256 / G) * (256 / G);            // whole groups stay together through the shuffles
     for (long m = ((long)blockIdx.x * 256 + threadIdx.x) / G; m < Mr; m += (long)gridDim.x * (256 / G)) {
-        float acc[CRF_MAXC];
+        float acc[CS];
 #pragma unroll
-        for (int c = 0; c < CRF_MAXC; ++c) acc[c] = 0.f;
+        for (int c = 0; c < CS; ++c) acc[c] = 0.f;
         const bool live = m < *M;
         const int s0 = live ? start[m] : 0, n = live ? cnt[m] : 0;
         for (int j = sub; j < n; j += G) {
-            const long px = ent[s0 + j];
-            const float w = entw[s0 + j];                         // (already times scale[px] when the filter's input is scaled: entws)
+            const int2 r = rec[s0 + j];
+            const float w = __int_as_float(r.y);
+            float v[CS];
+            if (in) {
 #pragma unroll
-            for (int c = 0; c < CRF_MAXC; ++c)
-                if (c < CT) acc[c] += w * ((in && c < C) ? in[px * C + c] : 1.0f);
+                for (int q = 0; q < CS / 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(in + (long)r.x * CS + 4 * q);
+                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CS; ++c) v[c] = 1.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < CS; ++c) acc[c] += w * ((extra && c == C) ? 1.0f : v[c]);
         }
 #pragma unroll
-        for (int c = 0; c < CRF_MAXC; ++c)
-            if (c < CT) {
+        for (int c = 0; c < CS; ++c) {
 #pragma unroll
-                for (int o = G / 2; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
-            }
+            for (int o = G / 2; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+        }
         if (live && sub == 0) {
 #pragma unroll
-            for (int c = 0; c < CRF_MAXC; ++c)
-                if (c < CT) val[(m + 1) * CT + c] = acc[c];
+            for (int q = 0; q < CS / 4; ++q)
+                *reinterpret_cast<float4*>(val + (m + 1) * CS + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
     }
 }
 
-// entws = entw * norm[pixel]: every filter of the mean field scales its input by the lattice's norm - folded into the list weights once,
-// so the gather makes one scattered read per entry (the value) instead of two
-__global__ __launch_bounds__(256) void crf_prescale_kernel(const int* __restrict__ ent, const float* __restrict__ entw, const float* __restrict__ norm,
-                                                           float* __restrict__ entws, long nv) {
+// recs = {pixel, weight * norm[pixel]}: every filter of the mean field scales its input by the lattice's norm - folded into the list weights
+// once, so the gather makes one scattered read per entry (the value) instead of two
+__global__ __launch_bounds__(256) void crf_prescale_kernel(const int2* __restrict__ rec, const float* __restrict__ norm, int2* __restrict__ recs, long nv) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < nv) entws[e] = entw[e] * norm[ent[e]];
+    if (e < nv) {
+        const int2 r = rec[e];
+        recs[e] = make_int2(r.x, __float_as_int(__int_as_float(r.y) * norm[r.x]));
+    }
 }
 
 template <int D>
@@ -385,79 +395,95 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long 
     }
 }
 
+template <int CS>
 __global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ nbj,
-                                                       const int* __restrict__ M, int C, long val_stride) {
+                                                       const int* __restrict__ M, long val_stride) {
     src += (long)blockIdx.y * val_stride;
     dst += (long)blockIdx.y * val_stride;
-    const long total = (long)*M * C;                              // (the launch is sized for a typical lattice, not the worst case)
+    const long total = (long)*M * (CS / 4);                       // one thread per point and 4 channels (the launch is sized for a typical lattice)
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const long i = t / C;
-        const int c = (int)(t % C);
-        const int n1 = nbj[i * 2] + 1, n2 = nbj[i * 2 + 1] + 1;              // -1 -> row 0 (zeros)
-        dst[(i + 1) * C + c] = src[(i + 1) * C + c] + 0.5f * (src[(long)n1 * C + c] + src[(long)n2 * C + c]);
+        const long i = t / (CS / 4);
+        const int q = (int)(t % (CS / 4)) * 4;
+        const long n1 = nbj[i * 2] + 1, n2 = nbj[i * 2 + 1] + 1;              // -1 -> row 0 (zeros)
+        const float4 a = *reinterpret_cast<const float4*>(src + (i + 1) * CS + q);
+        const float4 b = *reinterpret_cast<const float4*>(src + n1 * CS + q);
+        const float4 c = *reinterpret_cast<const float4*>(src + n2 * CS + q);
+        *reinterpret_cast<float4*>(dst + (i + 1) * CS + q) =
+            make_float4(a.x + 0.5f * (b.x + c.x), a.y + 0.5f * (b.y + c.y), a.z + 0.5f * (b.z + c.z), a.w + 0.5f * (b.w + c.w));
     }
 }
 
-// slice: out[i * C + c] = scale_i * alpha * sum_r bary * val[(off + 1) * C + c]
-template <int D>
+// slice: out[i * CS + c] = scale_i * alpha * sum_r bary * val[(off + 1) * CS + c]
+template <int D, int CS>
 __global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ val, const float* __restrict__ scale, const int* __restrict__ off,
                                                         const float* __restrict__ bary, float* __restrict__ out, long N, int C, int sqrt_norm,
                                                         long val_stride, long out_stride, float* __restrict__ out2) {
-    // out2 != nullptr: the value rows carry C + 1 channels; the last one (the filtered norm, see crf_gather_kernel) goes to out2[i]
+    // out2 != nullptr: channel C of the value rows is the filtered norm (see crf_gather_kernel) and goes to out2[i].  out == the [pixel][CS]
+    // array of the filter's result, or - when C == 1 and sqrt_norm / a [pixel] output is wanted (the lattice norms) - a plain [pixel] array
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     val += (long)blockIdx.y * val_stride;
     out += (long)blockIdx.y * out_stride;
-    const int CT = C + (out2 ? 1 : 0);
     const float alpha = 1.0f / (1.0f + exp2f(-(float)D));
-    float acc[CRF_MAXC];
-    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    float acc[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) acc[c] = 0.f;
 #pragma unroll
     for (int r = 0; r <= D; ++r) {
-        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * CT;
-        const float w = bary[(long)i * (D + 1) + r];
-        for (int c = 0; c < CT; ++c) acc[c] += w * val[o + c] * alpha;
+        const long o = (long)(off[(long)i * (D + 1) + r] + 1) * CS;
+        const float w = bary[(long)i * (D + 1) + r] * alpha;
+#pragma unroll
+        for (int q = 0; q < CS / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(val + o + 4 * q);
+            acc[4 * q] += w * t.x; acc[4 * q + 1] += w * t.y; acc[4 * q + 2] += w * t.z; acc[4 * q + 3] += w * t.w;
+        }
     }
     const float sc = scale ? scale[i] : 1.0f;
-    for (int c = 0; c < C; ++c) {
-        float v = acc[c] * sc;
-        if (sqrt_norm) v = 1.0f / sqrtf(v + 1e-20f);                          // norm = 1 / sqrt(K 1 + 1e-20)
-        out[(long)i * C + c] = v;
+    if (out_stride == 0) {                                        // a per-pixel scalar output (the lattice norm / kn): channel 0
+        float v = acc[0] * sc;
+        if (sqrt_norm) v = 1.0f / sqrtf(v + 1e-20f);              // norm = 1 / sqrt(K 1 + 1e-20)
+        out[i] = v;
+        return;
     }
-    if (out2 && blockIdx.y == 0) out2[i] = acc[C] * sc;                       // (images that share the lattice produce the same value)
+#pragma unroll
+    for (int q = 0; q < CS / 4; ++q)
+        *reinterpret_cast<float4*>(out + i * CS + 4 * q) = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
+    if (out2 && blockIdx.y == 0) out2[i] = acc[C] * sc;           // (images that share the lattice produce the same value)
 }
 
 // U = -log([1 - p, p] + 1e-8);  Q = softmax(-U)   (prob [C][N] -> q1 [N][C], u [N][C][2])
 __global__ __launch_bounds__(256) void crf_init_kernel(const float* __restrict__ prob, float* __restrict__ q1, float* __restrict__ u, long NT, int N,
-                                                       int C, int W, int tw) {
+                                                       int C, int CS, int W, int tw) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;          // NT = images x N pixels of the batch; prob is [image][C][N]
     if (t >= NT * C) return;
     const long i = t / C;
     const int c = (int)(t % C);
+    const long e = i * CS + c;                                    // q1 [pixel][CS], u [pixel][CS][2]
     const float p = prob[((i / N) * C + c) * N + crf_raster((int)(i % N), W, tw)];
     const float u0 = -logf((1.0f - p) + 1e-8f), u1 = -logf(p + 1e-8f);
-    u[t * 2] = u0; u[t * 2 + 1] = u1;
+    u[e * 2] = u0; u[e * 2 + 1] = u1;
     const float t0 = -u0, t1 = -u1, mx = fmaxf(t0, t1);
     const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
-    q1[t] = e1 / (e0 + e1);
+    q1[e] = e1 / (e0 + e1);
 }
 
 // t_l = -U_l + wg * fg_l + wb * fb_l with f_1 = filtered Q1, f_0 = K(n) n - f_1;  Q1 = softmax;  last iteration: mask = 255 * (t1 > t0)
 __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict__ u, const float* __restrict__ fg, const float* __restrict__ fb,
                                                          const float* __restrict__ kng, const float* __restrict__ knb, float wg, float wb,
                                                          float* __restrict__ q1, unsigned char* __restrict__ mask, float* __restrict__ q_out,
-                                                         long NT, int N, int C, int W, int tw) {
+                                                         long NT, int N, int C, int CS, int W, int tw) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= NT * C) return;
     const long i = t / C;
     const int c = (int)(t % C);
-    const float g1 = fg[t], b1 = fb[t];
-    const float t0 = -u[t * 2] + wg * (kng[i % N] - g1) + wb * (knb[i] - b1);     // (the spatial lattice is one image's, shared)
-    const float t1 = -u[t * 2 + 1] + wg * g1 + wb * b1;
+    const long e = i * CS + c;
+    const float g1 = fg[e], b1 = fb[e];
+    const float t0 = -u[e * 2] + wg * (kng[i % N] - g1) + wb * (knb[i] - b1);     // (the spatial lattice is one image's, shared)
+    const float t1 = -u[e * 2 + 1] + wg * g1 + wb * b1;
     const float mx = fmaxf(t0, t1);
     const float e0 = expf(t0 - mx), e1 = expf(t1 - mx);
     const float q = e1 / (e0 + e1);
-    q1[t] = q;
+    q1[e] = q;
     const long o = ((i / N) * C + c) * N + crf_raster((int)(i % N), W, tw);
     if (mask) mask[o] = (e1 / (e0 + e1) > e0 / (e0 + e1)) ? 255 : 0;                          // argmax over [Q0, Q1], ties -> label 0
     if (q_out) q_out[o] = q;
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict
 
 struct CrfLattice {
     int* off; float* bary; unsigned long long* hkeys; int* hid; unsigned long long* pkeys; int* nb; float* norm; float* kn; int* M;
-    int* cnt; int* start; int* ent; float* entw; float* entws; int* cursor;   // per-point entry lists: pixel, weight (and weight x norm[pixel]) of every (pixel, vertex) pair
+    int* cnt; int* start; int2* rec; int2* recs; int* cursor;   // per-point entry lists: {pixel, weight} (and {pixel, weight x norm[pixel]}) of every (pixel, vertex) pair
     long cap, scap, mmax;             // big / front table slots (hkeys, hid hold scap + cap entries)
 };
 
@@ -505,17 +531,17 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
         lat[k].kn = L.carve<float>(base, npx[k]);
         lat[k].cnt = L.carve<int>(base, 2 * nv);              // counts per point, then the rank of every entry in its point's list
         lat[k].start = L.carve<int>(base, nv);
-        lat[k].ent = L.carve<int>(base, nv);
-        lat[k].entw = L.carve<float>(base, nv);
-        lat[k].entws = L.carve<float>(base, nv);
+        lat[k].rec = L.carve<int2>(base, nv);
+        lat[k].recs = L.carve<int2>(base, nv);
     }
-    const long vmax = (N * 6 + 1) * (long)(C + 1);               // (+1: the constant-one channel of the first mean-field filter)
+    const long CS = C + 1 <= 4 ? 4 : 8;                          // channel stride (the C maps + the norm channel of the first filter, padded)
+    const long vmax = (N * 6 + 1) * CS;
     val0 = L.carve<float>(base, vmax);
     val1 = L.carve<float>(base, vmax);
-    q1 = L.carve<float>(base, N * C);
-    u = L.carve<float>(base, N * C * 2);
-    fg = L.carve<float>(base, N * C);
-    fb = L.carve<float>(base, N * C);
+    q1 = L.carve<float>(base, N * CS);
+    u = L.carve<float>(base, N * CS * 2);
+    fg = L.carve<float>(base, N * CS);
+    fb = L.carve<float>(base, N * CS);
     flags = L.carve<int>(base, 8);            // M of the two lattices, key overflow flag, -, entry cursors of the two lattices
     lat[0].M = flags; lat[1].M = flags ? flags + 1 : nullptr;
     lat[0].cursor = flags ? flags + 4 : nullptr; lat[1].cursor = flags ? flags + 5 : nullptr;
@@ -529,24 +555,34 @@ unsigned crf_blocks(long work) {
 // One filter application K(scale_in * in) * scale_out over `nimg` images that share the lattice `lt` (N pixels each; in / out are
 // [image][pixel][C], scale arrays [pixel]): the bilateral lattice covers the whole batch (nimg = 1, N = all pixels), the spatial one is
 // one image's and serves every image of the batch through blockIdx.y.
-template <int D>
-void crf_filter(const CrfLattice& lt, const float* in, const float* scale_in, const float* scale_out, float* out, float* val0, float* val1, long N,
-                int C, int sqrt_norm, int nimg, hipStream_t s, float* out2 = nullptr) {
-    const int CT = C + (out2 ? 1 : 0);                          // out2: one more channel, the filter of the constant 1 (-> the lattice's kn)
-    const long vstride = (N * (D + 1) + 1) * (long)CT;
-    (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)CT * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
-    (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)CT * sizeof(float), nimg, s);
-    hipLaunchKernelGGL(crf_gather_kernel<D>, dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, scale_in, lt.start, lt.cnt, lt.ent,
-                       scale_in ? lt.entws : lt.entw, val0, lt.M, C, N * C, vstride, out2 ? 1 : 0);
+template <int D, int CS>
+void crf_filter_cs(const CrfLattice& lt, const float* in, bool scaled_in, const float* scale_out, float* out, bool scalar_out, float* val0, float* val1,
+                   long N, int C, int sqrt_norm, int nimg, hipStream_t s, float* out2) {
+    const long vstride = (N * (D + 1) + 1) * (long)CS;
+    (void)hipMemset2DAsync(val0, vstride * sizeof(float), 0, (size_t)CS * sizeof(float), nimg, s);   // row 0 = the zero "missing neighbour"
+    (void)hipMemset2DAsync(val1, vstride * sizeof(float), 0, (size_t)CS * sizeof(float), nimg, s);
+    hipLaunchKernelGGL((crf_gather_kernel<D, CS>), dim3(crf_blocks(N / 4), nimg), dim3(256), 0, s, in, lt.start, lt.cnt, scaled_in ? lt.recs : lt.rec, val0,
+                       lt.M, C, N * CS, vstride, out2 ? 1 : 0);
     float* a = val0;
     float* b = val1;
     for (int j = 0; j <= D; ++j) {
-        // lattice points are a fraction of the worst case N (D + 1): a grid-stride launch sized for N / 4 points per channel
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(crf_blocks(N / 4 * CT), nimg), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, CT, vstride);
+        // lattice points are a fraction of the worst case N (D + 1): a grid-stride launch sized for N / 4 points
+        hipLaunchKernelGGL(crf_blur_kernel<CS>, dim3(crf_blocks(N / 4 * (CS / 4)), nimg), dim3(256), 0, s, a, b, lt.nb + (long)j * lt.mmax * 2, lt.M, vstride);
         float* t = a; a = b; b = t;
     }
-    hipLaunchKernelGGL(crf_slice_kernel<D>, dim3((unsigned)((N + 255) / 256), nimg), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm,
-                       vstride, N * C, out2);
+    hipLaunchKernelGGL((crf_slice_kernel<D, CS>), dim3((unsigned)((N + 255) / 256), nimg), dim3(256), 0, s, a, scale_out, lt.off, lt.bary, out, N, C, sqrt_norm,
+                       vstride, scalar_out ? 0 : N * CS, out2);
+}
+
+// One filter application K(scale_in * in) * scale_out over `nimg` images that share the lattice `lt` (N pixels each; in / out are
+// [image][pixel][CS] with CS = 4 or 8 the padded channel count, or - scalar_out - a plain [pixel] array from channel 0; scale arrays
+// [pixel]): the bilateral lattice covers the whole batch (nimg = 1, N = all pixels), the spatial one is one image's and serves every image of
+// the batch through blockIdx.y.  in == nullptr: the constant 1.  out2: one more channel, the filter of the constant 1 (-> the lattice's kn).
+template <int D>
+void crf_filter(const CrfLattice& lt, const float* in, bool scaled_in, const float* scale_out, float* out, bool scalar_out, float* val0, float* val1, long N,
+                int C, int CS, int sqrt_norm, int nimg, hipStream_t s, float* out2 = nullptr) {
+    if (CS == 4) crf_filter_cs<D, 4>(lt, in, scaled_in, scale_out, out, scalar_out, val0, val1, N, C, sqrt_norm, nimg, s, out2);
+    else crf_filter_cs<D, 8>(lt, in, scaled_in, scale_out, out, scalar_out, val0, val1, N, C, sqrt_norm, nimg, s, out2);
 }
 
 template <int D>
@@ -563,12 +599,12 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
     hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.hid, lt.cnt, lt.cnt + nv, nv);
     hipLaunchKernelGGL(crf_alloc_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);
-    hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.ent, lt.entw, nv, D + 1);
+    hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.rec, nv, D + 1);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
-    crf_filter<D>(lt, nullptr, nullptr, nullptr, lt.norm, val0, val1, N, 1, 1, 1, s);
-    hipLaunchKernelGGL(crf_prescale_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.ent, lt.entw, lt.norm, lt.entws, nv);
+    crf_filter<D>(lt, nullptr, false, nullptr, lt.norm, true, val0, val1, N, 1, 4, 1, 1, s);
+    hipLaunchKernelGGL(crf_prescale_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.rec, lt.norm, lt.recs, nv);
     // (with_kn = false: the caller's first mean-field filter carries the constant-one channel along and writes kn itself)
-    if (with_kn) crf_filter<D>(lt, nullptr, lt.norm, lt.norm, lt.kn, val0, val1, N, 1, 0, 1, s);
+    if (with_kn) crf_filter<D>(lt, nullptr, true, lt.norm, lt.kn, true, val0, val1, N, 1, 4, 0, 1, s);
 }
 
 // largest |lattice coordinate| the features can produce: |elevated_j| <= sum_i cf_i + j cf_j, cf_i = fmax_i * scale_i (Permutohedral::init)
@@ -633,14 +669,16 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s, !ride);
     crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, tw, sxy_b, srgb, flags + 2, val0, val1, s, !ride);
     const long nc = NT * Ci;
-    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci, (int)W, tw);
+    const int CS = Ci + 1 <= 4 ? 4 : 8;                          // as in crf_carve
+    (void)hipMemsetAsync(q1, 0, (size_t)NT * CS * sizeof(float), s);          // (the padding channels are read - and ignored - by the vector loads)
+    hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci, CS, (int)W, tw);
     for (int it = 0; it < iters; ++it) {
         const bool first = ride && it == 0;
-        crf_filter<2>(lat[0], q1, lat[0].norm, lat[0].norm, fg, val0, val1, N, Ci, 0, (int)B, s, first ? lat[0].kn : nullptr);
-        crf_filter<5>(lat[1], q1, lat[1].norm, lat[1].norm, fb, val0, val1, NT, Ci, 0, 1, s, first ? lat[1].kn : nullptr);
+        crf_filter<2>(lat[0], q1, true, lat[0].norm, fg, false, val0, val1, N, Ci, CS, 0, (int)B, s, first ? lat[0].kn : nullptr);
+        crf_filter<5>(lat[1], q1, true, lat[1].norm, fb, false, val0, val1, NT, Ci, CS, 0, 1, s, first ? lat[1].kn : nullptr);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,
-                           q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci, (int)W, tw);
+                           q1, last ? mask : nullptr, last ? q_out : nullptr, NT, N, Ci, CS, (int)W, tw);
     }
     SS_LAUNCH_CHECK("dense_crf");
     return 0;
