@@ -210,40 +210,47 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     from simseg_amd import segpost
     post_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def step():
+    def encode(ev=None):
         with torch.no_grad():
             feats = model.forward_image_feature(images)                 # [B, 1024, 768]
             pooled = model.forward_image_project(feats)                 # [B, 512]
             tok = model.image_projection(feats)                         # [B, 1024, 512]
             sim = patch_text_similarity(tok, text, compute_dtype=cdt)   # [B, 1024, classes]
             scores = ops.gemm(pooled, text)                             # [B, classes]
-            # post-processing of tools/seg_evaluation.py:112-170 on the device (the CPU DenseCRF is outside the path)
-            post_ev[0].record()
-            out = segpost.segment(sim, scores, labels, img // 16, 10, hist=hist, want_pred=False, images_u8=images_u8 if crf else None)
-            post_ev[1].record()
-        return sim, scores, out
+            # post-processing of tools/seg_evaluation.py:112-170 on the device, first half: candidate classes + min-max maps
+            if ev is not None:
+                ev.record()
+            st = segpost.segment_begin(sim, scores, img // 16, 10, need_prob=crf)
+        return sim, scores, st
 
-    # Two batches in flight: consecutive batches go to alternating HIP streams, as a prefetching loader would issue them
-    # (tools/seg_eval_device.py does the same); one batch's attention / LayerNorm / post-processing phases fill the tile-grid
-    # tails of the other's GEMMs (measured: +7 % bf16, +2 % fp32 over one stream).  The histograms accumulate atomically.
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    def finish(enc):
+        with torch.no_grad():
+            out = segpost.segment_finish(enc[2], labels, hist=hist, want_pred=False, images_u8=images_u8 if crf else None)
+        return enc[0], enc[1], out
 
-    def run(n_batches):
-        cur = torch.cuda.current_stream()
-        out = None
-        for i in range(n_batches):
-            st = streams[i % 2]
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                out = step()
-        for st in streams:
-            cur.wait_stream(st)
+    def step():                      # one batch alone (the post-processing stage timed by itself)
+        enc = encode(post_ev[0])
+        out = finish(enc)
+        post_ev[1].record()
         return out
 
+    # Two batches in flight on two HIP streams, software-pipelined on the host as tools/seg_eval_device.py does (segpost.EvalPipeline):
+    # batch i's encoder is enqueued BEFORE batch i-1 is finished, so the DenseCRF stage's host read (the candidate table) finds its data
+    # long finished and the GPU has MFMA work queued while Python walks the stage's launch loop; one batch's attention / LayerNorm /
+    # post-processing phases fill the tile-grid tails of the other's GEMMs.  The histograms accumulate atomically.
+    def run(n_batches):
+        pipe = segpost.EvalPipeline(dev, lambda: encode(), lambda enc: finish(enc), pipelined=crf and os.environ.get("SIMSEG_SEG_PIPELINE", "1") != "0")
+        for _ in range(n_batches):
+            pipe.submit()
+        return pipe.flush()
+
     step()
+    torch.cuda.synchronize()
+    step()                           # post-processing alone: events around the second half of one batch, nothing else on the GPU
+    torch.cuda.synchronize()
+    post_ms = post_ev[0].elapsed_time(post_ev[1])
     run(2)
     torch.cuda.synchronize()
-    post_ev[0].synchronize()
     t0 = time.perf_counter()
     last = run(2 * steps)
     torch.cuda.synchronize()
@@ -258,7 +265,6 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     t = n_patches + 1
     fl = 12 * (24 * t * dim * dim + 4 * t * t * dim) + 2 * n_patches * 768 * dim + 2 * 2 * n_patches * dim * 512 + 2 * n_patches * 512 * classes
     wps = world * windows * steps / float(el)
-    post_ms = post_ev[0].elapsed_time(post_ev[1])
     # algorithmic bytes of the post stage: every VISITED candidate map (img x img bytes) is written once, read and written by the
     # fused dilate+erode, and read again for the argmax / IoU pass; the label map is read once per window.  (All five slots are
     # read by the argmax pass as the reference's temp_pred[...] stack would be: counted for visited ones only.)

@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
 // counter word serialises millions of same-address atomics).
 __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__ off, long nv, const unsigned long long* __restrict__ hkeys,
                                                          int* __restrict__ hid, unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
+    // (one range per BLOCK, not per wave: the counter is a single word and same-address atomics serialise - 24 k of them were most of this
+    // kernel's 124 us per 16-image lattice)
+    __shared__ int wsum[4];
+    __shared__ int bbase;
     const long e0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
     int slots[16];
     int n = 0;
@@ -241,9 +245,16 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__
         const int t = __shfl_up(incl, o, 64);
         if ((int)(threadIdx.x & 63) >= o) incl += t;
     }
-    int base = 0;
-    if ((threadIdx.x & 63) == 63 && incl) base = atomicAdd(M, incl);
-    int id = __shfl(base, 63, 64) + incl - n;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bbase = tot ? atomicAdd(M, tot) : 0;
+    }
+    __syncthreads();
+    int id = bbase + incl - n;
+    for (int k = 0; k < w; ++k) id += wsum[k];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (slots[j] < 0) {
@@ -294,18 +305,38 @@ __global__ __launch_bounds__(256) void crf_count_kernel(int* __restrict__ off, c
 }
 __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ cnt, int* __restrict__ start, const int* __restrict__ M,
                                                         int* __restrict__ cursor) {
-    const long m = (long)blockIdx.x * 256 + threadIdx.x;
-    const int n = m < *M ? cnt[m] : 0;
-    int incl = n;                                                 // inclusive prefix over the wave
+    // Grid-stride over the M points that exist (the launch cannot know M: sized for the worst case it ran 6 threads per pixel, nearly all
+    // idle), four points per thread, and ONE range per block from the single cursor word (27 k same-address atomics were the rest of this
+    // kernel's 125 us per 16-image lattice).  Lists of consecutive points stay consecutive inside a block's range.
+    __shared__ int wsum[4];
+    __shared__ int bbase;
+    const int Mv = *M;
+    for (long b0 = (long)blockIdx.x * 1024; b0 < Mv; b0 += (long)gridDim.x * 1024) {
+        const long m0 = b0 + threadIdx.x * 4;
+        int c[4], n = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if ((int)(threadIdx.x & 63) >= o) incl += t;
+        for (int j = 0; j < 4; ++j) { c[j] = m0 + j < Mv ? cnt[m0 + j] : 0; n += c[j]; }
+        int incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) incl += t;
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) wsum[w] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            bbase = tot ? atomicAdd(cursor, tot) : 0;
+        }
+        __syncthreads();
+        int s = bbase + incl - n;
+        for (int k = 0; k < w; ++k) s += wsum[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + j < Mv) { start[m0 + j] = s; s += c[j]; }
+        __syncthreads();                                          // wsum / bbase are rewritten by the next trip
     }
-    int base = 0;
-    if ((threadIdx.x & 63) == 63 && incl) base = atomicAdd(cursor, incl);
-    base = __shfl(base, 63, 64);
-    if (m < *M) start[m] = base + incl - n;
 }
 __global__ __launch_bounds__(256) void crf_fill_kernel(const int* __restrict__ off, const float* __restrict__ bary, const int* __restrict__ start,
                                                        const int* __restrict__ rank, int2* __restrict__ rec, long nv, int d1) {
@@ -598,7 +629,7 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, table, lt.nb, lt.mmax);
     (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
     hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.hid, lt.cnt, lt.cnt + nv, nv);
-    hipLaunchKernelGGL(crf_alloc_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);
+    hipLaunchKernelGGL(crf_alloc_kernel, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.cnt, lt.start, lt.M, lt.cursor);       // (1024 points per block and trip)
     hipLaunchKernelGGL(crf_fill_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, lt.off, lt.bary, lt.start, lt.cnt + nv, lt.rec, nv, D + 1);
     // norm = 1 / sqrt(K 1 + 1e-20);  kn = norm * K(norm)   (the filtered constant-one channel of the symmetric normalisation)
     crf_filter<D>(lt, nullptr, false, nullptr, lt.norm, true, val0, val1, N, 1, 4, 1, 1, s);

@@ -43,7 +43,7 @@ def crf_masks(prob, cand_idx, images_u8, chunk=None, scale=1, static=None, **par
         m, _ = ops.dense_crf(images_u8.contiguous(), up.contiguous(), **dict(CRF_PARAMS, **params))
         return m * (cand_idx >= 0).to(torch.uint8)[:, :, None, None]
     if chunk is None:
-        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "16"))
+        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "32"))      # (16 -> 32: 25.5 -> 24.7 ms per 63-window batch of 512^2, 9.9 -> 9.1 ms at 288^2; 64 no better)
     masks = torch.zeros(B, K, H, W, device=dev, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
@@ -65,16 +65,19 @@ def crf_masks(prob, cand_idx, images_u8, chunk=None, scale=1, static=None, **par
     return masks
 
 
-def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand=5, ignore_index=255, refine=None, hist=None,
-            want_pred=True, closing=True, images_u8=None):
-    """sim [B,n*n,C] fp32, scores [B,C], labels [B,H,W] uint8 -> dict(pred, hist, cand_idx, cand_score, threshold).
-    images_u8 [B,16n,16n,3] uint8 (RGB): run the reference's DenseCRF on every visited candidate map."""
-    C = sim.shape[2]
-    num_classes = num_classes or C
+def segment_begin(sim, scores, num_patch, top_cls_num, ncand=5, need_prob=False):
+    """First half of segment(): candidate selection and the per-candidate min-max maps - device work only, nothing is read back."""
     cand_idx, cand_score, thr = ops.seg_select(scores, top_cls_num, ncand)
-    need_prob = refine is not None or images_u8 is not None
     masks, prob = ops.seg_masks(sim, cand_idx, num_patch, want_prob=need_prob)
-    if need_prob:
+    return {"cand_idx": cand_idx, "cand_score": cand_score, "threshold": thr, "masks": masks, "prob": prob, "num_patch": num_patch,
+            "num_classes": sim.shape[2]}
+
+
+def segment_finish(st, labels, num_classes=None, ignore_index=255, refine=None, hist=None, want_pred=True, closing=True, images_u8=None):
+    """Second half of segment(): DenseCRF (ONE host read of the candidate table), closing, resize + argmax + IoU histograms."""
+    cand_idx, cand_score, masks, prob, num_patch = st["cand_idx"], st["cand_score"], st["masks"], st["prob"], st["num_patch"]
+    num_classes = num_classes or st["num_classes"]
+    if refine is not None or images_u8 is not None:
         B, K, N = prob.shape
         lo = prob.view(B, K, num_patch, num_patch)
         if refine is not None:
@@ -85,15 +88,21 @@ def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand
     if closing:
         masks = ops.close7(masks, cand_idx.reshape(-1))                       # cv2.dilate then cv2.erode (:156-157), visited slots only
     pred, hist = ops.seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index, hist=hist, want_pred=want_pred)
-    return {"pred": pred, "hist": hist, "cand_idx": cand_idx, "cand_score": cand_score, "threshold": thr, "masks": masks}
+    return {"pred": pred, "hist": hist, "cand_idx": cand_idx, "cand_score": cand_score, "threshold": st["threshold"], "masks": masks}
 
 
-def eval_batch(model, image, label, text, top_cls_num, hist=None, crf=True, mean=None, std=None, sim_dtype=None, refine=None,
-               want_pred=False):
-    """One batch of the zero-shot segmentation evaluation, everything on the device (tools/seg_evaluation.py:99-170 for every image of
-    the batch at once): towers -> pooled embedding + projected patch tokens -> similarity map for all classes -> segment().
-    image [B,3,S,S] normalised network input, label [B,H,W] uint8, text [C,512] unit-norm class embeddings.  crf: run the DenseCRF on
-    the de-normalised input (image * std + mean, :104) as the reference does; hist [3,C] int64 accumulates."""
+def segment(sim, scores, labels, num_patch, top_cls_num, num_classes=None, ncand=5, ignore_index=255, refine=None, hist=None,
+            want_pred=True, closing=True, images_u8=None):
+    """sim [B,n*n,C] fp32, scores [B,C], labels [B,H,W] uint8 -> dict(pred, hist, cand_idx, cand_score, threshold).
+    images_u8 [B,16n,16n,3] uint8 (RGB): run the reference's DenseCRF on every visited candidate map."""
+    st = segment_begin(sim, scores, num_patch, top_cls_num, ncand, need_prob=refine is not None or images_u8 is not None)
+    return segment_finish(st, labels, num_classes or sim.shape[2], ignore_index, refine, hist, want_pred, closing, images_u8)
+
+
+def encode_batch(model, image, text, top_cls_num, crf=True, mean=None, std=None, sim_dtype=None, refine=None):
+    """Everything of eval_batch() up to the candidate maps: towers -> pooled embedding + projected patch tokens -> similarity map for all
+    classes -> candidate selection + min-max maps.  Device work only (no host read): the caller may enqueue the NEXT batch's encoder
+    before it finishes this one (EvalPipeline)."""
     from .heads import patch_text_similarity
     feats = model.forward_image_feature(image)                    # [B, n*n, D]
     pooled = model.forward_image_project(feats)                   # [B, 512]
@@ -102,7 +111,92 @@ def eval_batch(model, image, label, text, top_cls_num, hist=None, crf=True, mean
     raw = None
     if crf and refine is None:
         raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
-    return segment(sim, ops.gemm(pooled.float(), text), label, n, top_cls_num, hist=hist, want_pred=want_pred, refine=refine, images_u8=raw)
+    st = segment_begin(sim, ops.gemm(pooled.float(), text), n, top_cls_num, need_prob=refine is not None or raw is not None)
+    st["images_u8"] = raw
+    return st
+
+
+def finish_batch(st, label, hist=None, refine=None, want_pred=False):
+    return segment_finish(st, label, hist=hist, want_pred=want_pred, refine=refine, images_u8=st.get("images_u8"))
+
+
+def eval_batch(model, image, label, text, top_cls_num, hist=None, crf=True, mean=None, std=None, sim_dtype=None, refine=None,
+               want_pred=False):
+    """One batch of the zero-shot segmentation evaluation, everything on the device (tools/seg_evaluation.py:99-170 for every image of
+    the batch at once): towers -> pooled embedding + projected patch tokens -> similarity map for all classes -> segment().
+    image [B,3,S,S] normalised network input, label [B,H,W] uint8, text [C,512] unit-norm class embeddings.  crf: run the DenseCRF on
+    the de-normalised input (image * std + mean, :104) as the reference does; hist [3,C] int64 accumulates."""
+    st = encode_batch(model, image, text, top_cls_num, crf=crf, mean=mean, std=std, sim_dtype=sim_dtype, refine=refine)
+    return finish_batch(st, label, hist=hist, refine=refine, want_pred=want_pred)
+
+
+class EvalPipeline:
+    """Software-pipelined evaluation: batch i's ENCODER is enqueued before batch i-1 is finished, and the finishing stage runs on its
+    own HIGH-PRIORITY stream.  The DenseCRF stage needs one host read (the candidate table) and then issues ~100 small dependent
+    launches per chunk from a Python loop; run back to back with its own encoder, the GPU idles through that loop (6 of the 23 ms the
+    stage took per 63-window batch of 512^2).  Here the encoders alternate between two normal-priority streams (two batches in flight:
+    one's attention / LayerNorm phases fill the tile-grid tails of the other's GEMMs), so MFMA work is always queued, and the stage's
+    small kernels take the CUs they need as soon as a GEMM tile retires (without the priority a chain of small dependent kernels
+    queues behind whole GEMM launches of the other stream: measured 3x slower end to end in fp32).  Same work per batch, same results
+    (the histograms accumulate atomically: no ordering between batches is needed).
+    Memory: a batch's intermediate tensors are produced under an encoder stream and read by the finishing stream.  They are kept
+    referenced here until an event behind the finishing stage has completed (no record_stream: that defers the allocator's reuse of
+    every marked block and sent each batch back to hipMalloc), at most `depth` batches deep."""
+
+    def __init__(self, device, encode, finish, depth=3, pipelined=True):
+        # pipelined = False: whole batches on the two alternating streams, each finished right behind its encoder - the better order when
+        # the finishing stage has no host read and no long chain of small launches (no DenseCRF: 3071 vs 2927 windows/s, ViT-B bf16 512^2)
+        self.pipelined = pipelined
+        lo, hi = 0, -1
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()
+        except Exception:       # noqa: BLE001  (older torch: the documented default range)
+            pass
+        self.enc_streams = [torch.cuda.Stream(device=device, priority=lo) for _ in range(2)]
+        self.post_stream = torch.cuda.Stream(device=device, priority=hi)
+        self.encode, self.finish, self.depth = encode, finish, depth
+        self.i, self.pending, self.last, self.retire = 0, None, None, []
+
+    def _reap(self, keep):
+        while self.retire and (len(self.retire) > keep or self.retire[0][0].query()):
+            self.retire[0][0].synchronize()
+            self.retire.pop(0)
+
+    def submit(self, *batch):
+        self._reap(self.depth)
+        cur = torch.cuda.current_stream()
+        st = self.enc_streams[self.i % 2]
+        self.i += 1
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            enc = self.encode(*batch)
+            ev = torch.cuda.Event()
+            ev.record()
+            if not self.pipelined:
+                self.last = self.finish(enc, *batch)
+                return
+        prev, self.pending = self.pending, (ev, enc, batch)
+        if prev is not None:
+            self._finish(prev)
+
+    def _finish(self, item):
+        ev, enc, batch = item
+        self.post_stream.wait_event(ev)
+        with torch.cuda.stream(self.post_stream):
+            self.last = self.finish(enc, *batch)
+            done = torch.cuda.Event()
+            done.record()
+        self.retire.append((done, enc, batch))
+
+    def flush(self):
+        if self.pending is not None:
+            self._finish(self.pending)
+            self.pending = None
+        self._reap(0)
+        cur = torch.cuda.current_stream()
+        for st in self.enc_streams + [self.post_stream]:
+            cur.wait_stream(st)
+        return self.last
 
 
 def iou_from_hist(hist):

@@ -160,3 +160,35 @@ def test_miou_gate_hip_pipeline_vs_oracle_loop(case, monkeypatch):
     assert report["fp32"][2] >= 0.999 and report["fp32"][3] <= 0.5, report
     assert abs(report["bf16"][1]) <= 0.1, report
     assert report["bf16"][3] <= 1.0, report
+
+
+def test_pipelined_evaluation_equals_batch_by_batch(monkeypatch):
+    """segpost.EvalPipeline (what tools/seg_eval_device.py and bench.py run: batch i's encoder enqueued on the other stream before batch
+    i-1 is finished) accumulates exactly the histograms of eval_batch() called batch by batch on one stream."""
+    from simseg_amd import segpost
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    S, C, top, B, nb = 288, 21, 10, 3, 5
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(C, 512, generator=g), dim=-1).cuda()
+    model = _build("vit_test_patch16", 128, "bert-test", 128, S, seed=5).eval().cuda()
+    mean = torch.tensor(MEAN, device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor(STD, device="cuda").view(1, 3, 1, 1)
+    batches = []
+    for i in range(nb):
+        _, x = _voc_like(B, S, seed=40 + i)
+        lab = torch.randint(0, C, (B, S, S), generator=g, dtype=torch.int64).to(torch.uint8)
+        batches.append((x.cuda(), lab.cuda()))
+    want = torch.zeros(3, C, device="cuda", dtype=torch.int64)
+    with torch.no_grad():
+        for x, lab in batches:
+            segpost.eval_batch(model, x, lab, text, top, hist=want, crf=True, mean=mean, std=std)
+    got = torch.zeros(3, C, device="cuda", dtype=torch.int64)
+    pipe = segpost.EvalPipeline(torch.device("cuda", 0), lambda x, lab: segpost.encode_batch(model, x, text, top, crf=True, mean=mean, std=std),
+                                lambda st, x, lab: segpost.finish_batch(st, lab, hist=got))
+    with torch.no_grad():
+        for x, lab in batches:
+            pipe.submit(x, lab)
+        pipe.flush()
+    torch.cuda.synchronize()
+    assert int(want[2].sum()) == nb * B * S * S
+    assert torch.equal(got, want)

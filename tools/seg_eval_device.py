@@ -135,25 +135,28 @@ def main():
         mean = torch.tensor(cfg.transforms.normalize.mean, device=ENV.device).view(1, 3, 1, 1)
         std = torch.tensor(cfg.transforms.normalize.std, device=ENV.device).view(1, 3, 1, 1)
         count, t0 = 0, time.perf_counter()
-        # consecutive batches alternate between two HIP streams (two batches in flight: one's attention / LayerNorm / post-processing
-        # fills the GEMM tails of the other); the histograms accumulate atomically, so no ordering between batches is needed
-        streams = [torch.cuda.Stream(device=ENV.device) for _ in range(2)]
-        cur = torch.cuda.current_stream()
+        # two batches in flight on two HIP streams, the next batch's encoder enqueued before the previous batch is finished
+        # (segpost.EvalPipeline: the CRF stage's host read and its Python launch loop run under queued MFMA work); the histograms
+        # accumulate atomically, so no ordering between batches is needed
+        def encode(image, label):
+            refine = None
+            if args.host_crf and not args.no_crf:
+                refine = host_crf_refine((((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy())
+            # (the de-normalised input is what the tool hands to dense_crf, tools/seg_evaluation.py:104)
+            st = segpost.encode_batch(model, image, text, top_cls_num, crf=not args.no_crf, mean=mean, std=std, refine=refine)
+            st["refine"] = refine
+            return st
+
+        def finish(st, image, label):
+            return segpost.finish_batch(st, label, hist=hist, refine=st["refine"])
+
+        pipe = segpost.EvalPipeline(ENV.device, encode, finish, pipelined=not args.no_crf)
         with torch.no_grad():
-            for i, (image, label) in enumerate(batches(name)):
+            for image, label in batches(name):
                 image, label = image.to(ENV.device), label.to(ENV.device)
-                st = streams[i % 2]
-                st.wait_stream(cur)
-                image.record_stream(st); label.record_stream(st)
-                with torch.cuda.stream(st):
-                    refine = None
-                    if args.host_crf and not args.no_crf:
-                        refine = host_crf_refine((((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy())
-                    # (the de-normalised input is what the tool hands to dense_crf, tools/seg_evaluation.py:104)
-                    segpost.eval_batch(model, image, label, text, top_cls_num, hist=hist, crf=not args.no_crf, mean=mean, std=std, refine=refine)
+                pipe.submit(image, label)
                 count += image.shape[0]
-        for st in streams:
-            cur.wait_stream(st)
+            pipe.flush()
         torch.cuda.synchronize()
         iou, miou = segpost.iou_from_hist(hist)
         dt = time.perf_counter() - t0
