@@ -189,6 +189,12 @@ int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32
 
 int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);
+/* fp32 [rows, K] (row stride ld_in) -> bf16 [rows, 6 K]: the three round-to-nearest bf16 pieces hi / mid / lo of every element
+ * (hi + mid + lo == x), laid out along K as [hi|hi|hi|mid|mid|lo] (b_pattern = 0, the A operand) or [hi|mid|lo|hi|mid|hi] (b_pattern = 1,
+ * the B operand), so that ONE simseg_gemm call on the two bf16 images forms the six leading piece products of the fp32 product in its
+ * fp32 accumulators - the exact-mode nn.Linear of the evaluation tools (torch fp32 matmul, vit_builder.py:18 / huggingface_builder.py:16-17
+ * without autocast) at the bf16 MFMA rate; the three dropped products are <= 2^-24 |a||b|, the size of an fp32 FMA's own rounding. */
+int simseg_split_bf16x3(const float* in, void* out, int64_t rows, int64_t K, int64_t ld_in, int b_pattern, void* stream);
 /* dst[i,:] = src[idx[i],:] (idx[i] < 0: a zero row); rows of row_bytes (a multiple of 16) bytes, any dtype.  Drops / restores the padded
  * token rows of ragged caption batches around the text tower's GEMMs (HF BertModel computes them: huggingface_builder.py:16-17). */
 int simseg_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t row_bytes, void* stream);

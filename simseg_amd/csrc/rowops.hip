@@ -587,6 +587,42 @@ inline int grid_for(long n, int block, int cap = 4096) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// ---- fp32 operand -> three bf16 pieces, laid out for ONE bf16 GEMM that reproduces the fp32 product -----------------------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three round-to-nearest pieces of 8 significant
+// bits each carry x's 24 (bf16 has fp32's exponent range, so the residuals are exact and in range).  A product a.b is then the sum
+// of nine piece products; the three smallest (mid.lo, lo.mid, lo.lo <= 2^-24 |a||b|) are dropped, like the rounding of the fp32 FMA
+// chain they replace.  The six kept ones are laid out along K - the A operand as [hi | hi | hi | mid | mid | lo], the B operand as
+// [hi | mid | lo | hi | mid | hi], K' = 6 K - so that one launch of the bf16 MFMA kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// forms all of them in its accumulators: six times the MFMA work at sixteen times the matrix rate of v_mfma_f32_32x32x2_f32.
+// One thread per 8 consecutive k of a row: 32 B in, six 16-byte stores out.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long rows, int K, long ld_in, int bpat) {
+    const int kc = K >> 3;
+    const long total = rows * kc;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / kc;
+        const int k0 = (int)(t - r * kc) << 3;
+        const float4 a = *reinterpret_cast<const float4*>(in + r * ld_in + k0), b = *reinterpret_cast<const float4*>(in + r * ld_in + k0 + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        union { bf16_t h[8]; u32x4 v; } hi, mid, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi.h[e] = (bf16_t)x[e];
+            const float r1 = x[e] - (float)hi.h[e];
+            mid.h[e] = (bf16_t)r1;
+            lo.h[e] = (bf16_t)(r1 - (float)mid.h[e]);
+        }
+        bf16_t* o = out + r * (6L * K) + k0;
+        // A pattern: hi hi hi mid mid lo;  B pattern: hi mid lo hi mid hi
+        *reinterpret_cast<u32x4*>(o) = hi.v;
+        *reinterpret_cast<u32x4*>(o + K) = bpat ? mid.v : hi.v;
+        *reinterpret_cast<u32x4*>(o + 2L * K) = bpat ? lo.v : hi.v;
+        *reinterpret_cast<u32x4*>(o + 3L * K) = bpat ? hi.v : mid.v;
+        *reinterpret_cast<u32x4*>(o + 4L * K) = mid.v;
+        *reinterpret_cast<u32x4*>(o + 5L * K) = bpat ? hi.v : lo.v;
+    }
+}
+
 }  // namespace
 
 #define STREAM ((hipStream_t)stream)
@@ -788,6 +824,17 @@ extern "C" int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, vo
     else
         hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)in, (float*)out, (long)(n / 4));
     SS_LAUNCH_CHECK("cast");
+    return 0;
+}
+
+extern "C" int simseg_split_bf16x3(const float* in, void* out, int64_t rows, int64_t K, int64_t ld_in, int b_pattern, void* stream) {
+    SS_CHECK(in && out, "split_bf16x3: null pointer");
+    SS_CHECK(K > 0 && K % 8 == 0 && ld_in >= K && ld_in % 4 == 0, "split_bf16x3: K must be a multiple of 8 (got %lld)", (long long)K);
+    SS_CHECK(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "split_bf16x3: operands must be 16-byte aligned");
+    if (rows <= 0) return 0;
+    const int grid = grid_for(rows * (K / 8), 256, 16384);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid), dim3(256), 0, STREAM, in, (bf16_t*)out, (long)rows, (int)K, (long)ld_in, b_pattern);
+    SS_LAUNCH_CHECK("split_bf16x3");
     return 0;
 }
 

@@ -273,6 +273,19 @@ def cast(x, dtype, out=None):
     return out
 
 
+def split_bf16x3(x2d, b_pattern=False):
+    """fp32 [rows, K] -> bf16 [rows, 6 K]: the hi / mid / lo bf16 pieces of every element along K, in the A-operand order (hi hi hi mid mid
+    lo) or the B-operand order (hi mid lo hi mid hi): gemm(split(a), split(b, True)) is the fp32 product a @ b^T formed on the bf16 MFMA
+    pipe in fp32 accumulators (include/simseg_hip.h: simseg_split_bf16x3)."""
+    require_gpu(x2d)
+    rows, K = x2d.shape
+    if x2d.stride(1) != 1:
+        raise ValueError("split_bf16x3 needs unit-stride rows")
+    out = torch.empty(rows, 6 * K, device=x2d.device, dtype=torch.bfloat16)
+    call("simseg_split_bf16x3", ptr(x2d), ptr(out), rows, K, x2d.stride(0), int(bool(b_pattern)), stream())
+    return out
+
+
 def transpose_f32(x2d):
     require_gpu(x2d)
     R, C = x2d.shape

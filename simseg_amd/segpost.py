@@ -130,6 +130,25 @@ def eval_batch(model, image, label, text, top_cls_num, hist=None, crf=True, mean
     return finish_batch(st, label, hist=hist, refine=refine, want_pred=want_pred)
 
 
+_PIPE_STREAMS = {}
+
+
+def _pipeline_streams(device):
+    """Two normal-priority encoder streams + one high-priority finishing stream per device, created ONCE per process: the runtime maps
+    streams onto a few hardware queues when they are created, and two streams that land on one queue serialise - a fresh set per
+    evaluation made the finishing stage's luck (its own queue, or behind an encoder's) vary from call to call."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _PIPE_STREAMS.get(key)
+    if st is None:
+        lo, hi = 0, -1
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()
+        except Exception:       # noqa: BLE001  (older torch: the documented default range)
+            pass
+        st = _PIPE_STREAMS[key] = ([torch.cuda.Stream(device=device, priority=lo) for _ in range(2)], torch.cuda.Stream(device=device, priority=hi))
+    return st
+
+
 class EvalPipeline:
     """Software-pipelined evaluation: batch i's ENCODER is enqueued before batch i-1 is finished, and the finishing stage runs on its
     own HIGH-PRIORITY stream.  The DenseCRF stage needs one host read (the candidate table) and then issues ~100 small dependent
@@ -147,13 +166,7 @@ class EvalPipeline:
         # pipelined = False: whole batches on the two alternating streams, each finished right behind its encoder - the better order when
         # the finishing stage has no host read and no long chain of small launches (no DenseCRF: 3071 vs 2927 windows/s, ViT-B bf16 512^2)
         self.pipelined = pipelined
-        lo, hi = 0, -1
-        try:
-            lo, hi = torch.cuda.Stream.priority_range()
-        except Exception:       # noqa: BLE001  (older torch: the documented default range)
-            pass
-        self.enc_streams = [torch.cuda.Stream(device=device, priority=lo) for _ in range(2)]
-        self.post_stream = torch.cuda.Stream(device=device, priority=hi)
+        self.enc_streams, self.post_stream = _pipeline_streams(torch.device(device))
         self.encode, self.finish, self.depth = encode, finish, depth
         self.i, self.pending, self.last, self.retire = 0, None, None, []
 

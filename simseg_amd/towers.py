@@ -33,6 +33,7 @@ def invalidate_weight_cache():
     carry their own version counter); load_state_dict / copy_ / optimizers / .to() are detected without it."""
     _W16.clear()
     _CAT.clear()
+    _W3.clear()
 
 
 def _wt(w, adt):
@@ -51,6 +52,71 @@ def _wt(w, adt):
                 del _W16[k]
         _W16[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), w16)
     return w16
+
+
+# ---- exact-mode forward GEMMs on the bf16 matrix pipe ---------------------------------------------------------------------------
+# gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16 vs v_mfma_f32_32x32x2_f32, both accumulating in fp32).
+# An fp32 value is exactly the sum of three bf16 pieces, so the fp32 product of the evaluation tools' nn.Linear layers is formed by ONE
+# bf16 GEMM over the six leading piece products laid out along K (ops.split_bf16x3): six times the MFMA work at sixteen times the rate,
+# with the error of the three dropped products (<= 2^-24 |a||b|) at the level of the fp32 FMA chain's own rounding.  Used for forward
+# passes that save nothing for a backward (the evaluation tools; training in exact mode keeps the fp32 kernels, whose operands the
+# backward re-reads) and only where the 256x256 bf16 kernel has at least a round of tiles to work on.
+_SPLIT_FP32 = os.environ.get("SIMSEG_AMD_SPLIT_FP32", "auto")      # 0 = never, 1 = wherever the shapes allow (tests), auto
+_W3 = {}       # id(parameter) -> (weakref(parameter), parameter._version, parameter.data_ptr(), split copy [out, 6 in])
+SPLIT_CALLS = [0]
+
+
+def _split_ok(M, N, K):
+    if _SPLIT_FP32 == "0" or K % 64 or N % 8 or M < 256 or N < 128:
+        return False
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return _SPLIT_FP32 == "1" or tiles >= 192
+
+
+def _wt_split(w):
+    ent = _W3.get(id(w))
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].shape[0] == w.shape[0]:
+        return ent[3]
+    w3 = ops.split_bf16x3(w.detach().reshape(w.shape[0], -1).contiguous(), b_pattern=True)
+    if isinstance(w, torch.nn.Parameter):
+        if len(_W3) > 4096:
+            for k in [k for k, e in _W3.items() if e[0]() is None]:
+                del _W3[k]
+        _W3[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), w3)
+    return w3
+
+
+def _fwd_gemm(x2d, w, adt, saving, **kw):
+    """x2d @ w^T for an nn.Linear weight `w` [out, in] in the forward pass: the activation-dtype kernel, or - exact mode, nothing saved for
+    a backward, enough tiles - the split-bf16 form of the same fp32 product."""
+    if adt == F32 and not saving and x2d.dtype == F32 and _split_ok(x2d.shape[0], w.shape[0], x2d.shape[1]):
+        SPLIT_CALLS[0] += 1
+        kw.setdefault("out_dtype", F32)
+        return ops.gemm(ops.split_bf16x3(x2d), _wt_split(w), **kw)
+    return ops.gemm(x2d, _wt(w, adt) if w.dim() == 2 else _wt(w.reshape(w.shape[0], -1), adt), **kw)
+
+
+import threading
+
+_GRAD_MODE = threading.local()
+
+
+class _GradAwareFn(Function):
+    """autograd switches grad mode OFF inside Function.forward, and ctx.needs_input_grad reports the inputs' requires_grad flags whatever
+    the caller's mode: a forward cannot tell torch.no_grad() evaluation from training by itself.  The caller's mode is recorded here, on
+    the way in."""
+
+    @classmethod
+    def apply(cls, *args):
+        _GRAD_MODE.on = torch.is_grad_enabled()
+        return super().apply(*args)
+
+
+def _saving(ctx):
+    """Does this forward need to keep anything for a backward?  Under torch.no_grad() - every evaluation tool - the parameters still
+    'need' gradients as far as ctx.needs_input_grad is concerned, and the blocks used to save statistics, log-sum-exps and GELU
+    derivatives nobody would read."""
+    return getattr(_GRAD_MODE, "on", True) and any(ctx.needs_input_grad)
 
 
 def _as_one(*ts):
@@ -189,7 +255,7 @@ def _take_shadow(t32):
 # ------------------------------------------------------------------------------------------------------------------
 # generic pieces
 # ------------------------------------------------------------------------------------------------------------------
-class LinearFn(Function):
+class LinearFn(_GradAwareFn):
     """y = x W^T (+ b) on [..., in] -> [..., out]; fp32 in / fp32 out at the module boundary."""
 
     @staticmethod
@@ -197,9 +263,11 @@ class LinearFn(Function):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous()
         xa = x2 if adt == F32 else ops.cast(x2, BF16)
+        ctx.adt, ctx.has_b, ctx.shp = adt, b is not None, shp
+        if not _saving(ctx):      # evaluation: nothing saved (exact mode: the split-bf16 form where the problem is large)
+            return _fwd_gemm(xa, w, adt, False, bias=None if b is None else b.detach(), out_dtype=F32).view(*shp[:-1], w.shape[0])
         wa = _wt(w, adt)
         y = ops.gemm(xa, wa, bias=None if b is None else b.detach(), out_dtype=F32)
-        ctx.adt, ctx.has_b, ctx.shp = adt, b is not None, shp
         ctx.save_for_backward(xa, wa)
         return y.view(*shp[:-1], w.shape[0])
 
@@ -233,7 +301,7 @@ class LayerNormFn(Function):
 # ------------------------------------------------------------------------------------------------------------------
 # ViT
 # ------------------------------------------------------------------------------------------------------------------
-class ViTEmbedFn(Function):
+class ViTEmbedFn(_GradAwareFn):
     """patch_embed -> cat(cls) -> + pos_embed  (vit_builder.py:14-17) -> fp32 residual stream [B,1+N,D]."""
 
     @staticmethod
@@ -244,9 +312,9 @@ class ViTEmbedFn(Function):
         if pos.shape[1] != N + 1:
             raise ValueError(f"pos_embed has {pos.shape[1]} tokens but the {H}x{W} input makes {N + 1}")
         cols = ops.vit_im2col(image.contiguous().float(), adt)
-        w2 = _wt(pw.reshape(D, 768), adt)
         x = torch.empty(B, N + 1, D, device=image.device, dtype=F32)
-        ops.gemm(cols, w2, bias=pb.detach(), residual=pos.detach().reshape(N + 1, D), row_group=N, res_mod=True, out=x.view(-1, D))
+        _fwd_gemm(cols, pw, adt, _saving(ctx), bias=pb.detach(), residual=pos.detach().reshape(N + 1, D), row_group=N, res_mod=True,
+                  out=x.view(-1, D))
         ops.vit_cls_rows(cls.detach().reshape(-1), pos.detach().reshape(-1), x)
         ctx.adt, ctx.dims = adt, (B, N, D)
         ctx.save_for_backward(cols)
@@ -272,15 +340,22 @@ class ViTEmbedFn(Function):
         return None, dw, db, dcls, dpos, None
 
 
-class ViTBlockFn(Function):
+class ViTBlockFn(_GradAwareFn):
     """timm Block: x + proj(attn(norm1 x)); then + fc2(gelu(fc1(norm2 .)))   (pre-LN, eps 1e-6, erf GELU)."""
 
     @staticmethod
     def forward(ctx, x, heads, adt, n1w, n1b, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
         B, T, D = x.shape
         x = x.contiguous()
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         ln1, _, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), 1e-6, out_dtype=adt, save_stats=save)
+        if not save:        # evaluation: no operand is kept (exact mode: large problems go through the split-bf16 form of the fp32 products)
+            qkv = _fwd_gemm(ln1.view(-1, D), qw, adt, False, bias=qb.detach())
+            att, _ = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=False)
+            x1 = _fwd_gemm(att.view(-1, D), pw, adt, False, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
+            ln2, _, _, _ = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=False)
+            act = _fwd_gemm(ln2, f1w, adt, False, bias=f1b.detach(), act=1)
+            return _fwd_gemm(act, f2w, adt, False, bias=f2b.detach(), residual=x1, out_dtype=F32).view(B, T, D)
         qw_, pw_, f1w_, f2w_ = _wt(qw, adt), _wt(pw, adt), _wt(f1w, adt), _wt(f2w, adt)
         qkv = ops.gemm(ln1.view(-1, D), qw_, bias=qb.detach())
         att, lse = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=save)
@@ -452,7 +527,7 @@ def ragged_rows(mask):
 _PACKED_ATTN = os.environ.get("SIMSEG_AMD_PACKED_ATTN", "1") != "0"      # (A/B switch: attention on the packed rows)
 
 
-class BertLayerFn(Function):
+class BertLayerFn(_GradAwareFn):
     """HF BertLayer (post-LN, eps 1e-12): a = LN(x + drop(dense(attn(x)))); y = LN(a + drop(dense(gelu(dense(a)))))."""
 
     @staticmethod
@@ -465,7 +540,7 @@ class BertLayerFn(Function):
         B, L = mask.shape
         D = x.shape[-1]
         x = x.contiguous()
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         # (bf16: the previous layer's output LayerNorm has written a bf16 copy of x next to the fp32 rows - no cast pass)
         sh16 = getattr(x, "_simseg_fwd16", None) if adt == BF16 else None
         if sh16 is not None and sh16[1] == x._version and sh16[0].numel() == x.numel():
@@ -490,12 +565,12 @@ class BertLayerFn(Function):
             attd = att
             if packed:
                 att = ops.gather_rows(att.view(-1, D), idx)          # [Nv, D]
-        s1 = ops.gemm(att.view(-1, D), ow_, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
+        s1 = _fwd_gemm(att.view(-1, D), ow, adt, save, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
         aa = a32 if adt == F32 else a16
         pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
-        act = ops.gemm(aa, iw_, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
-        s2 = ops.gemm(act, o2w_, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
+        act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
+        s2 = _fwd_gemm(act, o2w, adt, save, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt == BF16 and packed), save_stats=save)
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
@@ -610,7 +685,7 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
 # ------------------------------------------------------------------------------------------------------------------
 # heads
 # ------------------------------------------------------------------------------------------------------------------
-class ProjectPoolFn(Function):
+class ProjectPoolFn(_GradAwareFn):
     """SimpleProjection -> TopKPooling(LoDA) -> L2norm  (pipelines/clip.py:87-93, 111-120) as one node:
     the [B,N,512] token projection lives only inside this function."""
 
@@ -619,10 +694,13 @@ class ProjectPoolFn(Function):
         B, N, D = feats.shape
         f2 = feats.contiguous().view(-1, D)
         fa = f2 if adt == F32 else ops.cast(f2, BF16)
+        ctx.adt, ctx.k, ctx.dims = adt, k, (B, N, D)
+        if not _saving(ctx):
+            tok = _fwd_gemm(fa, w, adt, False).view(B, N, w.shape[0])
+            return ops.topk_pool_l2norm_fwd(tok, k, mask)[0]
         wa = _wt(w, adt)
         tok = ops.gemm(fa, wa).view(B, N, w.shape[0])
         emb, idx, norm = ops.topk_pool_l2norm_fwd(tok, k, mask)
-        ctx.adt, ctx.k, ctx.dims = adt, k, (B, N, D)
         ctx.save_for_backward(fa, wa, emb, idx, norm)
         return emb
 
