@@ -22,6 +22,11 @@ extern "C" {
 #endif
 
 int simseg_version(void);
+/* Which 16-bit type the calling thread's next calls compute in: 1 = bf16 (default), 2 = IEEE fp16 - the type of the reference's AMP mode
+ * (torch.cuda.amp.autocast() + GradScaler, simseg/tasks/clip/clip_runner.py:226-230, core/hooks/optimizer.py:73-82).  dtype code 1
+ * ("bf16") in every signature below means "the selected 16-bit type"; both flavours are the same kernels (v_mfma_f32_32x32x16_bf16 /
+ * _f16, fp32 accumulation).  Thread-local. */
+int simseg_set_half_type(int t);
 const char* simseg_last_error(void);
 
 /* C[M,N] = epilogue(alpha * opA(A) . opB(B)).  transA=0: A is [M,K]; 1: [K,M].  transB=0: B is [N,K] (nn.Linear

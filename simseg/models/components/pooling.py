@@ -44,7 +44,7 @@ class TopKPooling(nn.Module):
     def forward(self, x, attention_mask=None):
         k = clip_k_to_shortest(self.k, attention_mask)
         mask = None if attention_mask is None else attention_mask.contiguous().long()
-        return _TopKPool.apply(x if x.dtype in (torch.float32, torch.bfloat16) else x.float(), k, mask)
+        return _TopKPool.apply(x if x.dtype in (torch.float32, torch.bfloat16, torch.float16) else x.float(), k, mask)
 
 
 class AvgPooling(nn.Module):

@@ -16,6 +16,15 @@ int simseg_set_error(const char* fmt, ...) {
 extern "C" const char* simseg_last_error(void) { return g_simseg_err; }
 extern "C" int simseg_version(void) { return 100; }
 
+// 1 = bf16 (default), 2 = IEEE fp16: which flavour of the 16-bit kernels the calling thread's next calls run (dtype code 1 = "the selected
+// 16-bit type" everywhere in the ABI).  Thread-local like the kernel selectors.
+thread_local int g_ss_half = 1;
+extern "C" int simseg_set_half_type(int t) {
+    if (t != 1 && t != 2) return simseg_set_error("simseg_set_half_type: 1 (bf16) or 2 (fp16), got %d", t);
+    g_ss_half = t;
+    return 0;
+}
+
 // ---- probe: records which LDS element every lane receives from ds_read_b64_tr_b16 ---------------
 // LDS holds iota (element i = i) as 16-bit values; lane l supplies the byte address  l * 8.
 __global__ void tr16_probe_kernel(int* out) {

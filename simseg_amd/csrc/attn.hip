@@ -626,12 +626,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (two) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
-                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
+                s[0] = SS_MFMA_32x32x16(kf[kk], qr[kk], s[0], 0, 0, 0);
+                s[1] = SS_MFMA_32x32x16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) s[0] = SS_MFMA_32x32x16(kf[kk], qr[kk], s[0], 0, 0, 0);
         }
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[1] += t1 - dt0; dt0 = t1; }
         if (MASK) softmax_tile_lean<true, false>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, o, KT);
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
+                        o[db] = SS_MFMA_32x32x16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
                 }
             }
         }
@@ -839,8 +839,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 __builtin_amdgcn_sched_barrier(0);      // all fragments requested before the first MFMA (one LDS round trip, not eight)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qr[kk], s[0], 0, 0, 0);
-                    if (two) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
+                    s[0] = SS_MFMA_32x32x16(kf[kk], qr[kk], s[0], 0, 0, 0);
+                    if (two) s[1] = SS_MFMA_32x32x16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
                 }
             }
             if (EDGE && qt + nw < q32) load_q(qt + nw);      // Q of the next pass: lands under this tile's softmax, PV and stores
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
+                        o[db] = SS_MFMA_32x32x16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
                 }
             }
         };
@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
+            s = SS_MFMA_32x32x16(aq[kk], kr[kk], s, 0, 0, 0);
+            dp = SS_MFMA_32x32x16(ag[kk], vr[kk], dp, 0, 0, 0);
         }
         // requested while the MFMAs run: lse / delta of this lane's 16 query rows, and the transposed dO / Q fragments
         float4 l4[4], d4[4];
@@ -1132,8 +1132,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
             for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)pd[8 * s2 + e]; df[e] = (bf16_t)ds[8 * s2 + e]; }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
+                dv[db] = SS_MFMA_32x32x16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
+                dk[db] = SS_MFMA_32x32x16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
             }
         }
         if (more) {
@@ -1220,8 +1220,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[kk], qr[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kk], gr[kk], dp, 0, 0, 0);
+                s = SS_MFMA_32x32x16(ak[kk], qr[kk], s, 0, 0, 0);
+                dp = SS_MFMA_32x32x16(av[kk], gr[kk], dp, 0, 0, 0);
             }
             float4 b4[4];                                 // key bias of this lane's 16 key rows
 #pragma unroll
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) df[e] = (bf16_t)ds[8 * s2 + e];
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) dq[db] = SS_MFMA_32x32x16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
             }
         }
         if (more) {
@@ -1381,8 +1381,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
+                s = SS_MFMA_32x32x16(aq[kk], kr[kk], s, 0, 0, 0);
+                dp = SS_MFMA_32x32x16(ag[kk], vr[kk], dp, 0, 0, 0);
             }
             // requested while the MFMAs run: lse / delta of this lane's 16 query rows, and the transposed dO / Q fragments
             float4 l4[4], d4[4];
@@ -1424,8 +1424,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_res_kernel(AttnParams p) 
                 for (int e = 0; e < 8; ++e) { pf[e] = (bf16_t)pd[8 * s2 + e]; df[e] = (bf16_t)ds[8 * s2 + e]; }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
+                    dv[db] = SS_MFMA_32x32x16(gf[s2 * 2 + db], pf, dv[db], 0, 0, 0);
+                    dk[db] = SS_MFMA_32x32x16(qf[s2 * 2 + db], df, dk[db], 0, 0, 0);
                 }
             }
         }
@@ -1533,8 +1533,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[kk], qr[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kk], gr[kk], dp, 0, 0, 0);
+                s = SS_MFMA_32x32x16(ak[kk], qr[kk], s, 0, 0, 0);
+                dp = SS_MFMA_32x32x16(av[kk], gr[kk], dp, 0, 0, 0);
             }
             float4 b4[4];                                 // key bias of this lane's 16 key rows
 #pragma unroll
@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_res_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) df[e] = (bf16_t)ds[8 * s2 + e];
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) dq[db] = SS_MFMA_32x32x16(kf[s2 * 2 + db], df, dq[db], 0, 0, 0);
             }
         }
         if (qvalid) {
@@ -1776,8 +1776,8 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kr[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vr[kk], dp, 0, 0, 0);
+                s = SS_MFMA_32x32x16(aq[kk], kr[kk], s, 0, 0, 0);
+                dp = SS_MFMA_32x32x16(ag[kk], vr[kk], dp, 0, 0, 0);
             }
             // the rest in two halves of 16 query rows (MFMA step s2): lse / delta of the rows, the transposed dO / Q fragments, the
             // exponentials, then dV^T[d][key] += dO^T[d][q] . P[q][key] and dK^T[d][key] += Q^T[d][q] . dS[q][key].  (All 32 rows at
@@ -1826,8 +1826,8 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                 }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[db], pf, dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[db], df, dk[db], 0, 0, 0);
+                    dv[db] = SS_MFMA_32x32x16(gf[db], pf, dv[db], 0, 0, 0);
+                    dk[db] = SS_MFMA_32x32x16(qf[db], df, dk[db], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1852,7 +1852,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
                 u.hq.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + s2 * 16 * ONE_TP));
                 u.hq.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + s2 * 16 * ONE_TP + 8 * ONE_TP));
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s2 * 2 + db], u.v, dq[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) dq[db] = SS_MFMA_32x32x16(kf[s2 * 2 + db], u.v, dq[db], 0, 0, 0);
             }
         }
     }
@@ -2003,6 +2003,9 @@ extern "C" int simseg_debug_attn_occupancy(int64_t T) {
 }
 
 extern "C" int simseg_set_attention_variant(int v) {
+#ifndef SS_HALF
+    simseg_set_attention_variant_h16(v);      // the fp16 flavour keeps its own (thread-local) selector
+#endif
     g_attn_variant = v;
     return 0;
 }
@@ -2011,6 +2014,7 @@ extern "C" int simseg_set_attention_variant(int v) {
 extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B,
                                     int64_t T, int64_t H, float scale, uint64_t drop_seed, float drop_p, int skip_padded_rows,
                                     void* stream) {
+    SS_HALF_FWD(simseg_attention_fwd, qkv, key_mask, out, lse, dtype, B, T, H, scale, drop_seed, drop_p, skip_padded_rows, stream);
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
     p.pack = skip_padded_rows && key_mask && dtype == 1 && T <= RES_MAXT;
@@ -2062,6 +2066,7 @@ extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int
 extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout, const float* lse,
                                     float* workspace, void* dqkv, float* dqkv_colsum, int dtype, int64_t B, int64_t T, int64_t H, float scale,
                                     uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream) {
+    SS_HALF_FWD(simseg_attention_bwd, qkv, key_mask, out, dout, lse, workspace, dqkv, dqkv_colsum, dtype, B, T, H, scale, drop_seed, drop_p, skip_padded_rows, stream);
     float* delta = workspace;
     AttnParams p;
     if (int rc = fill_params(p, qkv, key_mask, B, T, H, scale, drop_seed, drop_p)) return rc;
@@ -2126,6 +2131,7 @@ extern "C" int simseg_attention_bwd(const void* qkv, const int64_t* key_mask, co
 // dense entry points: for prefix masks the same probabilities are dropped.  bf16 only.
 extern "C" int simseg_attention_fwd_rows(const void* qkv, const int32_t* row_start, void* out, float* lse, int64_t B, int64_t T, int64_t H,
                                          float scale, uint64_t drop_seed, float drop_p, void* stream) {
+    SS_HALF_FWD(simseg_attention_fwd_rows, qkv, row_start, out, lse, B, T, H, scale, drop_seed, drop_p, stream);
     AttnParams p;
     if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
     SS_CHECK(out && row_start, "attention_fwd_rows: null pointer");
@@ -2140,6 +2146,7 @@ extern "C" int simseg_attention_fwd_rows(const void* qkv, const int32_t* row_sta
 extern "C" int simseg_attention_bwd_rows(const void* qkv, const int32_t* row_start, const void* out, const void* dout, const float* lse,
                                          float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H, float scale,
                                          uint64_t drop_seed, float drop_p, void* stream) {
+    SS_HALF_FWD(simseg_attention_bwd_rows, qkv, row_start, out, dout, lse, workspace, dqkv, dqkv_colsum, B, T, H, scale, drop_seed, drop_p, stream);
     AttnParams p;
     if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
     SS_CHECK(out && dout && lse && workspace && dqkv && row_start, "attention_bwd_rows: null pointer");

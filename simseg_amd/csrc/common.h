@@ -5,9 +5,30 @@
 #include <stdio.h>
 #include <string.h>
 
+// The 16-bit operand type.  gemm.hip, attn.hip, rowops.hip and loss.hip are compiled TWICE (simseg_amd/build.py): as they stand - bf16, the
+// headline mode - and with -DSS_HALF, where the same sources are the IEEE fp16 flavour the reference's AMP mode uses (fp16 autocast + a
+// live GradScaler, clip_runner.py:226-230): `bf16_t` is then _Float16, the MFMA is v_mfma_f32_32x32x16_f16, and every C-ABI entry point
+// the file defines carries the suffix _h16 (half_names.h renames them by macro).  The bf16 build's entry points hand a call over to their
+// _h16 twin while the calling thread has selected fp16 (simseg_set_half_type(2)); dtype code 1 always means "the selected 16-bit type".
+#ifdef SS_HALF
+typedef _Float16 bf16_t;
+#define SS_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#else
 typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define SS_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4;
+#include "half_names.h"
+#ifndef SS_HALF
+extern thread_local int g_ss_half;          // 1 = bf16 (default), 2 = fp16: simseg_set_half_type
+#define SS_HALF_FWD(name, ...)                                  \
+    do {                                                        \
+        if (g_ss_half == 2) return name##_h16(__VA_ARGS__);     \
+    } while (0)
+#else
+#define SS_HALF_FWD(name, ...)
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -34,6 +55,11 @@ int simseg_set_error(const char* fmt, ...);
 
 // ---- numeric helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float half_bits_to_float(short bits) {      // a 16-bit operand that travelled as raw bits (transposing LDS reads)
+    union { short s; bf16_t h; } u;
+    u.s = bits;
+    return (float)u.h;
+}
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
 // Normal CDF for the erf-GELU epilogues.  libm's erff costs ~30 VALU instructions per element, which made the GELU / GELU'

@@ -138,7 +138,7 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b)
     if constexpr (sizeof(T) == 2) {
         union { u32x4 v; bf16x8 h; } ua, ub;
         ua.v = a; ub.v = b;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+        acc = SS_MFMA_32x32x16(ua.h, ub.h, acc, 0, 0, 0);
     } else {
         union { u32x4 v; float f[4]; } ua, ub;
         ua.v = a; ub.v = b;
@@ -922,7 +922,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
                 const s16x4 tR = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 64));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float al = __uint_as_float((unsigned)(unsigned short)tL[e] << 16), ar = __uint_as_float((unsigned)(unsigned short)tR[e] << 16);
+                    const float al = half_bits_to_float(tL[e]), ar = half_bits_to_float(tR[e]);
                     l[4 * q + e] = (acc[i][0][4 * q + e] * p.alpha + bL) * al;
                     r[4 * q + e] = (acc[i][1][4 * q + e] * p.alpha + bR) * ar;
                     sL += l[4 * q + e]; sR += r[4 * q + e];
@@ -1776,13 +1776,17 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
 
 // which kernel the calling thread's last simseg_gemm launched: 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS ring,
 // 3 = 256x256 ping-pong, 4 = small-problem kernel (the measurement code labels its per-kernel timings with this instead of re-deriving the dispatch rule)
-extern "C" int simseg_gemm_last_variant(void) { return g_gemm_last_variant; }
+extern "C" int simseg_gemm_last_variant(void) {
+    SS_HALF_FWD(simseg_gemm_last_variant); return g_gemm_last_variant; }
 
 // debugging: the ping-pong kernel writes 5 x u64 per block (start / K loop start / K loop end / end wall-clock stamps at 100 MHz, HW_ID)
 extern "C" int simseg_debug_gemm_stagger(int ticks) { g_gemm_stagger = ticks; return 0; }
 extern "C" int simseg_debug_gemm_trace(void* buf) { g_gemm_debug_trace = static_cast<unsigned long long*>(buf); return 0; }
 
 extern "C" int simseg_set_gemm_variant(int v) {
+#ifndef SS_HALF
+    simseg_set_gemm_variant_h16(v);      // the fp16 flavour keeps its own (thread-local) selector
+#endif
     g_gemm_debug_skip_epilogue = v >= 100;
     g_gemm_variant = v % 100;
     return 0;
@@ -1793,6 +1797,7 @@ namespace {
 
 extern "C" int simseg_patch_text_sim(const void* x, const void* text, float* out, int64_t M, int64_t C, int64_t K, int dtype,
                                      float eps, int normalize, void* stream) {
+    SS_HALF_FWD(simseg_patch_text_sim, x, text, out, M, C, K, dtype, eps, normalize, stream);
     SS_CHECK(x && text && out, "patch_text_sim: null pointer");
     SS_CHECK(M > 0 && C > 0 && C <= 256 && K > 0 && M < (1ll << 31), "patch_text_sim: need 1 <= C <= 256 (got C=%lld)", (long long)C);
     SS_CHECK(dtype == 0 || dtype == 1, "patch_text_sim: dtype must be 0 (fp32) or 1 (bf16)");
@@ -1808,6 +1813,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
                            const float* bias, const float* rowscale, const float* residual, int64_t ldr, int act,
                            const void* aux, void* aux_out, int row_group, int res_mod, int accumulate, int splitk,
                            uint64_t drop_seed, float drop_p, float* colsum, void* stream) {
+    SS_HALF_FWD(simseg_gemm, A, B, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, transA, transB, alpha, bias, rowscale, residual, ldr, act, aux, aux_out, row_group, res_mod, accumulate, splitk, drop_seed, drop_p, colsum, stream);
     SS_CHECK(A && B && C, "simseg_gemm: null operand");
     SS_CHECK(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "simseg_gemm: bad shape %lld x %lld x %lld",
              (long long)M, (long long)N, (long long)K);

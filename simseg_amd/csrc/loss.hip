@@ -353,6 +353,7 @@ extern "C" int simseg_recall_counts(const int32_t* has_match, const int32_t* ran
 extern "C" int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
                                        int64_t n_chunks, int chunk, float beta1, float beta2, float eps, int64_t step,
                                        float grad_scale, void* stream) {
+    SS_HALF_FWD(simseg_adamw_multi_step, table, sizes, chunk_tid, chunk_off, n_chunks, chunk, beta1, beta2, eps, step, grad_scale, stream);
     SS_CHECK(table && sizes && chunk_tid && chunk_off, "adamw_multi_step: null pointer");
     SS_CHECK(step >= 1 && chunk > 0, "adamw_multi_step: bad step/chunk");
     if (n_chunks <= 0) return 0;
@@ -366,6 +367,7 @@ extern "C" int simseg_adamw_multi_step(const void* table, const int64_t* sizes, 
 
 extern "C" int simseg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    SS_HALF_FWD(simseg_adamw_step, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
     SS_CHECK(p && g && m && v, "adamw_step: null pointer");
     SS_CHECK(step >= 1, "adamw_step: step counts from 1");
     if (n <= 0) return 0;

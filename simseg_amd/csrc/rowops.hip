@@ -629,6 +629,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                                     void* y_bf16, float* mean, float* rstd, int64_t rows, int64_t D, float eps, void* stream) {
+    SS_HALF_FWD(simseg_layernorm_fwd, x, gamma, beta, y, out_dtype, y_bf16, mean, rstd, rows, D, eps, stream);
     SS_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_fwd: D=%lld must be a multiple of 4 and <= %d", (long long)D, LN_MAXC * 256);
     if (rows <= 0) return 0;
@@ -645,6 +646,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
                                     const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
                                     float* dgamma, float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D,
                                     uint64_t drop_seed, float drop_p, void* stream) {
+    SS_HALF_FWD(simseg_layernorm_bwd, dy_bf16, dy_f32, dres, x, mean, rstd, gamma, dx_f32, dx_bf16, dgamma, dbeta, dxsum, partials, rows, D, drop_seed, drop_p, stream);
     SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
@@ -673,6 +675,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
 extern "C" int64_t simseg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, 1024) * 3 * D * (int64_t)sizeof(float); }
 
 extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream) {
+    SS_HALF_FWD(simseg_colsum_accum, in, in_dtype, out, rows, N, ld, stream);
     SS_CHECK(in && out, "colsum: null pointer");
     SS_CHECK(N % 8 == 0 && ld % 8 == 0, "colsum: N and ld must be multiples of 8");
     if (rows <= 0) return 0;
@@ -694,6 +697,7 @@ extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int
 }
 
 extern "C" int simseg_vit_im2col(const float* image, void* cols, int out_dtype, int64_t B, int64_t H, int64_t W, void* stream) {
+    SS_HALF_FWD(simseg_vit_im2col, image, cols, out_dtype, B, H, W, stream);
     SS_CHECK(image && cols, "im2col: null pointer");
     SS_CHECK(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "im2col: H, W must be multiples of the 16x16 patch");
     const long total = B * (H / 16) * (W / 16) * 192;
@@ -750,6 +754,7 @@ extern "C" int64_t simseg_topk_pool_workspace_bytes(int64_t B, int64_t P, int k)
 extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int64_t* mask, float* emb, int32_t* idx, float* norm,
                                            float* scratch, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize,
                                            void* stream) {
+    SS_HALF_FWD(simseg_topk_pool_l2norm_fwd, tok, dtype, mask, emb, idx, norm, scratch, B, N, P, k, eps, normalize, stream);
     SS_CHECK(tok && emb && idx && norm, "topk_pool_fwd: null pointer");
     SS_CHECK(P % 64 == 0 && P <= 1024, "topk_pool_fwd: P=%lld must be a multiple of 64 and <= 1024", (long long)P);
     SS_CHECK(k >= 1 && k <= POOL_MAXK && k <= N, "topk_pool_fwd: k=%d out of range (1..%d, <= N)", k, POOL_MAXK);
@@ -781,6 +786,7 @@ extern "C" int simseg_topk_pool_l2norm_fwd(const void* tok, int dtype, const int
 
 extern "C" int simseg_topk_pool_l2norm_bwd(const float* demb, const float* emb, const float* norm, const int32_t* idx, void* dtok,
                                            int dtype, int64_t B, int64_t N, int64_t P, int k, float eps, int normalize, void* stream) {
+    SS_HALF_FWD(simseg_topk_pool_l2norm_bwd, demb, emb, norm, idx, dtok, dtype, B, N, P, k, eps, normalize, stream);
     SS_CHECK(demb && emb && norm && idx && dtok, "topk_pool_bwd: null pointer");
     SS_CHECK(P % 64 == 0 && P <= 1024 && k >= 1 && k <= POOL_MAXK, "topk_pool_bwd: bad P/k");
     if (B <= 0) return 0;
@@ -802,6 +808,7 @@ extern "C" int simseg_segment_mean_l2norm(const float* x, float* out, int64_t S,
 }
 
 extern "C" int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t rows, int64_t D, float eps, void* stream) {
+    SS_HALF_FWD(simseg_row_rnorm, x, dtype, rnorm, rows, D, eps, stream);
     SS_CHECK(x && rnorm, "row_rnorm: null pointer");
     SS_CHECK(D % 4 == 0, "row_rnorm: D must be a multiple of 4");
     if (rows <= 0) return 0;
@@ -815,6 +822,7 @@ extern "C" int simseg_row_rnorm(const void* x, int dtype, float* rnorm, int64_t 
 }
 
 extern "C" int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream) {
+    SS_HALF_FWD(simseg_cast, in, out, n, to_bf16, stream);
     SS_CHECK(in && out, "cast: null pointer");
     SS_CHECK(n % 4 == 0, "cast: element count must be a multiple of 4");
     if (n <= 0) return 0;
@@ -850,7 +858,7 @@ extern "C" int simseg_transpose_f32(const float* in, float* out, int64_t R, int6
 // Row gather: dst[i,:] = src[idx[i],:] for i < n (idx < 0: a zero row).  Rows are `chunks` 16-byte pieces wide; dtype-agnostic.
 // The text tower uses it to drop the padded token rows of a ragged caption batch before its GEMMs / LayerNorms and to put rows back
 // (idx = inverse map, -1 at padded positions -> zeros) around the attention kernels, which keep the dense [B, L] layout.
-__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, const int* __restrict__ idx, u32x4* __restrict__ dst,
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, const int* __restrict__ idx, u32x4* __restrict__ dst,
                                                           long n, int chunks) {
     const long total = n * chunks;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -876,6 +884,7 @@ extern "C" int simseg_gather_rows(const void* src, const int32_t* idx, void* dst
 }
 
 extern "C" int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream) {
+    SS_HALF_FWD(simseg_dropout_apply, g, dtype, n, seed, p, stream);
     SS_CHECK(g, "dropout_apply: null pointer");
     SS_CHECK(p >= 0.f && p < 1.f, "dropout_apply: p out of range");
     if (n <= 0 || p == 0.f) return 0;

@@ -154,10 +154,10 @@ def patch_text_similarity(patch_proj, text_feat, eps=1e-12, compute_dtype=F32):
     B, N, P = patch_proj.shape
     x = patch_proj.contiguous().view(B * N, P)
     t = text_feat.contiguous()
-    want = torch.bfloat16 if compute_dtype == torch.bfloat16 else F32
-    x = x if x.dtype == want else (ops.cast(x.float(), torch.bfloat16) if want == torch.bfloat16 else x.float())
-    t = t if t.dtype == want else (ops.cast(t.float(), torch.bfloat16) if want == torch.bfloat16 else t.float())
-    epc = 8 if want == torch.bfloat16 else 4
+    want = compute_dtype if compute_dtype in ops.HALF_TYPES else F32
+    x = x if x.dtype == want else (ops.cast(x.float(), want) if want != F32 else x.float())
+    t = t if t.dtype == want else (ops.cast(t.float(), want) if want != F32 else t.float())
+    epc = 8 if want != F32 else 4
     if t.shape[0] <= 256 and P % epc == 0:
         return ops.patch_text_sim(x, t, eps).view(B, N, t.shape[0])      # fused: x is read once
     rn = ops.row_rnorm(x, eps)                                           # > 256 classes: row scale in the GEMM epilogue

@@ -3,6 +3,7 @@ single source of truth for the C ABI.  There is no CPU fallback: `call()` raises
 import ctypes
 import os
 import re
+import threading
 
 import torch
 
@@ -56,10 +57,23 @@ def load():
     return _lib
 
 
+_HALF = threading.local()     # .seen: 16-bit flavour of the tensors handed to ptr() since the last call(); .cur: what this thread's library side is set to
+
+
+def note_half(dtype):
+    """A call whose 16-bit tensors do not pass through ptr() (pointer tables): say which flavour they are."""
+    if dtype is torch.float16:
+        _HALF.seen = 2
+    elif dtype is torch.bfloat16 and getattr(_HALF, "seen", 0) != 2:
+        _HALF.seen = 1
+
+
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL).  Remembers whether a bf16 or an fp16 tensor went by: dtype code 1 of the C ABI means
+    "the 16-bit type the calling thread selected" (simseg_set_half_type), and call() selects it from what its arguments were."""
     if t is None:
         return None
+    note_half(t.dtype)
     return t.data_ptr()
 
 
@@ -74,6 +88,13 @@ def raw(name, *args):
 
 def call(name, *args):
     lib = load()
+    seen = getattr(_HALF, "seen", 0)
+    if seen:
+        _HALF.seen = 0
+        if getattr(_HALF, "cur", 1) != seen:          # (thread-local on both sides: autograd's backward threads start at bf16 like the library)
+            if lib.simseg_set_half_type(seen) != 0:
+                raise RuntimeError(lib.simseg_last_error().decode())
+            _HALF.cur = seen
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {lib.simseg_last_error().decode()}")

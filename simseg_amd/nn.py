@@ -23,14 +23,22 @@ BERT_ARCH = {
 
 
 def compute_dtype():
-    """bf16 under torch.autocast (the reference trains under autocast, clip_runner.py:226-228) or when
-    SIMSEG_AMD_COMPUTE=bf16; exact fp32 otherwise (the eval tools run fp32)."""
+    """The 16-bit type torch.autocast is set to (the reference trains under autocast, clip_runner.py:226-228: fp16 there, with a
+    GradScaler; bf16 is this package's headline mode) or the one SIMSEG_AMD_COMPUTE names (bf16 / fp16); exact fp32 otherwise (the
+    eval tools run fp32)."""
     env = os.environ.get("SIMSEG_AMD_COMPUTE", "").lower()
     if env in ("bf16", "bfloat16"):
         return torch.bfloat16
+    if env in ("fp16", "float16", "half"):
+        return torch.float16
     if env in ("fp32", "float32"):
         return torch.float32
-    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+    if torch.is_autocast_enabled():
+        try:
+            return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
+        except Exception:       # noqa: BLE001  (older torch)
+            return torch.float16 if torch.get_autocast_gpu_dtype() == torch.float16 else torch.bfloat16
+    return torch.float32
 
 
 _seed_state = [0x5EED]

@@ -8,14 +8,15 @@ import torch
 from .lib import call, ptr, require_gpu, stream, raw
 
 F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: BF16}       # code 1 = "the 16-bit type": bf16, or fp16 while the call's tensors are fp16 (lib.call)
+HALF_TYPES = (torch.bfloat16, torch.float16)
 
 
 def dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError(f"simseg_amd supports fp32 and bf16 tensors, got {t.dtype}")
+        raise TypeError(f"simseg_amd supports fp32, bf16 and fp16 tensors, got {t.dtype}")
 
 
 def _c(t):
@@ -64,6 +65,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
     kb = b.shape[0] if trans_b else b.shape[1]
     if kb != K:
         raise ValueError(f"gemm: inner dims differ ({K} vs {kb})")
+    if a.dtype != b.dtype or (aux is not None and aux.dtype not in (a.dtype, torch.float32)):
+        raise TypeError(f"gemm: operands of different types ({a.dtype}, {b.dtype}{'' if aux is None else ', aux ' + str(aux.dtype)}): bf16 and fp16 do not mix in one call")
     if out is None:
         rows = out_rows if out_rows is not None else M
         out = torch.empty(rows, N, device=a.device, dtype=out_dtype or a.dtype)
@@ -91,7 +94,8 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, want_bf16_copy=F
     D = x.shape[-1]
     rows = x.numel() // D
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
-    y16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16_copy else None
+    # (want_bf16_copy: False, True = a bf16 copy, or the 16-bit dtype the copy should have)
+    y16 = torch.empty(x.shape, device=x.device, dtype=want_bf16_copy if isinstance(want_bf16_copy, torch.dtype) else torch.bfloat16) if want_bf16_copy else None
     mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
     call("simseg_layernorm_fwd", ptr(_c(x)), ptr(gamma), ptr(beta), ptr(y), dt(y), ptr(y16), ptr(mean), ptr(rstd), rows, D,
@@ -105,7 +109,8 @@ def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dre
     D = x.shape[-1]
     rows = x.numel() // D
     dx32 = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_f32 else None
-    dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    h16 = dy16.dtype if dy16 is not None else (want_bf16 if isinstance(want_bf16, torch.dtype) else torch.bfloat16)
+    dx16 = torch.empty(x.shape, device=x.device, dtype=h16) if want_bf16 else None
     partials = torch.empty(raw("simseg_layernorm_bwd_workspace_bytes", rows, D) // 4, device=x.device, dtype=torch.float32)
     call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
          ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(partials), rows, D, int(drop_seed), float(drop_p), stream())
@@ -209,7 +214,7 @@ def attention_fwd_rows(qkv, heads, row_start, max_len, scale=0.125, save_lse=Fal
     """Ragged batch without padding: qkv [rows, 3*H*64] bf16, sequence b = rows [row_start[b], row_start[b+1]) (int32 [B+1]), at most
     max_len tokens each -> ctx [rows, H*64] (rows outside every sequence - a tile padding behind row n_real - are zeros), lse [B,H,max_len]."""
     require_gpu(qkv, row_start)
-    if qkv.dtype != torch.bfloat16 or row_start.dtype != torch.int32:
+    if qkv.dtype not in HALF_TYPES or row_start.dtype != torch.int32:
         raise TypeError("attention_fwd_rows: bf16 qkv, int32 row_start")
     rows, W = qkv.shape
     B = row_start.numel() - 1
@@ -269,7 +274,7 @@ def cast(x, dtype, out=None):
     require_gpu(x)
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=dtype)
-    call("simseg_cast", ptr(_c(x)), ptr(out), x.numel(), int(dtype == torch.bfloat16), stream())
+    call("simseg_cast", ptr(_c(x)), ptr(out), x.numel(), int(dtype in HALF_TYPES), stream())
     return out
 
 

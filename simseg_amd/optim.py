@@ -14,7 +14,7 @@ checkpoints (core/hooks/checkpoint.py:14-45) load here and ours load there; the 
 import numpy as np
 import torch
 
-from .lib import call, ptr, stream
+from .lib import call, note_half, ptr, stream
 from .towers import register_w16
 
 CHUNK = 1 << 16
@@ -22,8 +22,11 @@ RING = 4
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3, half_dtype=torch.bfloat16):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if half_dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("half_dtype: torch.bfloat16 (headline mode) or torch.float16 (the reference's AMP type)")
+        self.half_dtype = half_dtype      # type of the 16-bit compute copies the kernel writes (what the towers' GEMMs read next step)
         self._step = 0
         self._plans = {}
 
@@ -37,7 +40,7 @@ class AdamW(torch.optim.Optimizer):
         total = sum(p.numel() for p in params)
         m = torch.zeros(total, device=dev, dtype=torch.float32)
         v = torch.zeros(total, device=dev, dtype=torch.float32)
-        p16 = torch.empty(total, device=dev, dtype=torch.bfloat16)
+        p16 = torch.empty(total, device=dev, dtype=self.half_dtype)
         o = 0
         for p in params:
             st = self.state[p]
@@ -103,6 +106,7 @@ class AdamW(torch.optim.Optimizer):
             ev = torch.cuda.Event()
             ev.record()
             plan["events"][slot] = ev
+            note_half(self.half_dtype)        # (the 16-bit copies are addressed through the table: tell the binding which flavour they are)
             call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
                  CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
             plan["keepalive"] = grads        # the kernel reads them asynchronously

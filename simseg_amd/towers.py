@@ -43,9 +43,9 @@ def _wt(w, adt):
     if adt == F32:
         return w.detach()
     ent = _W16.get(id(w))
-    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].shape == w.shape:
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].shape == w.shape and ent[3].dtype == adt:
         return ent[3]
-    w16 = ops.cast(w.detach().contiguous(), BF16)
+    w16 = ops.cast(w.detach().contiguous(), adt)
     if isinstance(w, torch.nn.Parameter):
         if len(_W16) > 4096:
             for k in [k for k, e in _W16.items() if e[0]() is None]:
@@ -143,7 +143,7 @@ def _wt_stacked(ws, adt):
     one = _as_one(*parts)
     if one is not None:
         return one
-    if adt == BF16:
+    if adt != F32:
         ents = [_W16.get(id(w)) for w in ws]
         hit = _CAT.get(id(ws[0]))
         if hit is not None and all(e is not None and e is h for e, h in zip(ents, hit[0])):
@@ -209,15 +209,15 @@ def _bgrad(dy, out=None):
 
 def _act_grad(t32, adt):
     """A gradient of the fp32 residual stream as a GEMM operand of the compute dtype."""
-    return t32 if adt == F32 else ops.cast(t32, BF16)
+    return t32 if adt == F32 else ops.cast(t32, adt)
 
 
 def _ln_bwd(adt, x, mean, rstd, w, dg, db, dy, dres=None, dy32=None, dxsum=None, drop=(0.0, 0)):
     """Backward of a LayerNorm whose input was `x`: dx = LN'(dy [+ dy32]) + dres.  Returns (dx fp32, dx in the compute dtype with the
     dropout mask `drop` = (p, seed) of the dense layer that produced x re-applied); column sums of the second go to dxsum (that
     layer's bias gradient).  In bf16 mode all of it is one kernel; in exact mode the pieces are separate launches."""
-    if adt == BF16:
-        return ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dy32=dy32, dres=dres, dxsum=dxsum, drop_seed=drop[1], drop_p=drop[0])
+    if adt != F32:
+        return ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dy32=dy32, dres=dres, dxsum=dxsum, drop_seed=drop[1], drop_p=drop[0], want_bf16=adt)
     if dy32 is not None:
         raise ValueError("exact mode: fold the second gradient into `dy` with the producing GEMM's residual epilogue")
     dx32, _ = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy, dres=dres, want_bf16=False)
@@ -241,12 +241,12 @@ def _put_shadow(t32, t16, colsum):
     t32._simseg_shadow = (t16, colsum, t32._version)
 
 
-def _take_shadow(t32):
+def _take_shadow(t32, adt=None):
     sh = getattr(t32, "_simseg_shadow", None)
     if sh is None:
         return None
     del t32._simseg_shadow
-    if sh[2] != t32._version or sh[0].numel() != t32.numel():
+    if sh[2] != t32._version or sh[0].numel() != t32.numel() or (adt is not None and sh[0].dtype != adt):
         return None
     SHADOW_HITS[0] += 1
     return sh
@@ -262,7 +262,7 @@ class LinearFn(_GradAwareFn):
     def forward(ctx, x, w, b, adt):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous()
-        xa = x2 if adt == F32 else ops.cast(x2, BF16)
+        xa = x2 if adt == F32 else ops.cast(x2, adt)
         ctx.adt, ctx.has_b, ctx.shp = adt, b is not None, shp
         if not _saving(ctx):      # evaluation: nothing saved (exact mode: the split-bf16 form where the problem is large)
             return _fwd_gemm(xa, w, adt, False, bias=None if b is None else b.detach(), out_dtype=F32).view(*shp[:-1], w.shape[0])
@@ -377,7 +377,7 @@ class ViTBlockFn(_GradAwareFn):
         adt = ctx.adt
         need = ctx.needs_input_grad
         dy = dy.contiguous()
-        sh = _take_shadow(dy) if adt == BF16 else None
+        sh = _take_shadow(dy, adt) if adt != F32 else None
         dy = dy.view(-1, D)
         if sh is not None:
             dy16, df2b = sh[0].view(-1, D), sh[1]
@@ -404,7 +404,7 @@ class ViTBlockFn(_GradAwareFn):
         dqw = _wgrad(dqkv, ln1.view(-1, D), dqw_z) if need[5] else None
         dx, dx16 = _ln_bwd(adt, x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dln1, dres=dx1_32, dxsum=dsum)
         dx = dx.view(B, T, D)
-        if adt == BF16:
+        if adt != F32:
             _put_shadow(dx, dx16, dsum)
         return (dx, None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
 
@@ -542,18 +542,18 @@ class BertLayerFn(_GradAwareFn):
         x = x.contiguous()
         save = _saving(ctx)
         # (bf16: the previous layer's output LayerNorm has written a bf16 copy of x next to the fp32 rows - no cast pass)
-        sh16 = getattr(x, "_simseg_fwd16", None) if adt == BF16 else None
+        sh16 = getattr(x, "_simseg_fwd16", None) if adt != F32 else None
         if sh16 is not None and sh16[1] == x._version and sh16[0].numel() == x.numel():
             xa = sh16[0].view(-1, D)
         else:
-            xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), BF16)
+            xa = x.view(-1, D) if adt == F32 else ops.cast(x.view(-1, D), adt)
         wqkv = _wt_stacked((qw, kw, vw), adt)                              # HF keeps three matrices; one fused [3D, D] GEMM here
         bqkv = _as_one(qb.detach(), kb.detach(), vb.detach())
         if bqkv is None:
             bqkv = torch.cat([qb.detach(), kb.detach(), vb.detach()])
         ow_, iw_, o2w_ = _wt(ow, adt), _wt(iw, adt), _wt(o2w, adt)
         qkv = ops.gemm(xa, wqkv, bias=bqkv)
-        rows = packed and cu is not None and adt == BF16             # attention straight on the packed rows
+        rows = packed and cu is not None and adt != F32             # attention straight on the packed rows
         if rows:
             att, lse = ops.attention_fwd_rows(qkv, heads, cu, L, scale=64 ** -0.5, save_lse=save, drop_seed=seed, drop_p=drop_p, n_real=nv)
             attd = None
@@ -566,12 +566,12 @@ class BertLayerFn(_GradAwareFn):
             if packed:
                 att = ops.gather_rows(att.view(-1, D), idx)          # [Nv, D]
         s1 = _fwd_gemm(att.view(-1, D), ow, adt, save, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
-        a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt == BF16), save_stats=save)
+        a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt if adt != F32 else False), save_stats=save)
         aa = a32 if adt == F32 else a16
         pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
         act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = _fwd_gemm(act, o2w, adt, save, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
-        y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt == BF16 and packed), save_stats=save)
+        y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt if (adt != F32 and packed) else False), save_stats=save)
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
         ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv
@@ -592,15 +592,15 @@ class BertLayerFn(_GradAwareFn):
         I = pre.shape[1]
         (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros(
             dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
-        ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt == BF16 else dy, dy32=dy if adt == BF16 else None,
+        ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt != F32 else dy, dy32=dy if adt != F32 else None,
                              dxsum=do2b, drop=(p, seed + 2))
         dpre = _dgrad(d2, o2w_, act=4, aux=pre, colsum=dib)
         do2w = _wgrad(d2, act, do2w_z) if need[18] else None
         # gradient reaching LN_a's output: through the intermediate dense (da) + the residual branch (ds2_32); bf16 mode adds them
         # inside the LayerNorm kernel, exact mode in the GEMM's residual epilogue
-        da = _dgrad(dpre, iw_) if adt == BF16 else _dgrad(dpre, iw_, residual=ds2_32)
+        da = _dgrad(dpre, iw_) if adt != F32 else _dgrad(dpre, iw_, residual=ds2_32)
         diw = _wgrad(dpre, aa, diw_z) if need[16] else None
-        ds1_32, d1 = _ln_bwd(adt, s1, mean_a, rstd_a, law, dlaw, dlab, da, dy32=ds2_32 if adt == BF16 else None, dxsum=dob,
+        ds1_32, d1 = _ln_bwd(adt, s1, mean_a, rstd_a, law, dlaw, dlab, da, dy32=ds2_32 if adt != F32 else None, dxsum=dob,
                              drop=(p, seed + 1))
         datt = _dgrad(d1, ow_)
         dow = _wgrad(d1, att.view(-1, D), dow_z) if need[12] else None
@@ -667,7 +667,7 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
             idx = inv = None                                        # nothing to drop
         else:
             x = RowMapFn.apply(x.view(-1, D), idx, inv)             # [Nv, D]
-            if _PACKED_ATTN and adt == BF16 and L <= 256:
+            if _PACKED_ATTN and adt != F32 and L <= 256:
                 cu = ragged_rows(mask)                              # None: a mask with a hole - attention through the dense layout
     for i, lyr in enumerate(m.encoder.layer):
         a, s = lyr.attention, lyr.attention.self
@@ -693,7 +693,7 @@ class ProjectPoolFn(_GradAwareFn):
     def forward(ctx, feats, w, k, mask, adt):
         B, N, D = feats.shape
         f2 = feats.contiguous().view(-1, D)
-        fa = f2 if adt == F32 else ops.cast(f2, BF16)
+        fa = f2 if adt == F32 else ops.cast(f2, adt)
         ctx.adt, ctx.k, ctx.dims = adt, k, (B, N, D)
         if not _saving(ctx):
             tok = _fwd_gemm(fa, w, adt, False).view(B, N, w.shape[0])

@@ -10,6 +10,7 @@ Differences that follow from the hardware path: 16-bit compute is bf16, so no lo
 of a checkpoint is written as an identity GradScaler state and ignored on load); the reference's per-step
 torch.cuda.empty_cache() (clip_runner.py:248-249) is not reproduced."""
 import math
+import os
 import re
 import time
 
@@ -56,14 +57,23 @@ def param_groups(model, cfg):
 
 
 class Trainer:
-    def __init__(self, model, cfg, steps_per_epoch, net=None):
-        """model: the bare CLIPModel; net: what is called (model or its DDP wrapper)."""
+    def __init__(self, model, cfg, steps_per_epoch, net=None, amp_dtype=None):
+        """model: the bare CLIPModel; net: what is called (model or its DDP wrapper).
+        amp_dtype ("bf16" default / "fp16", or SIMSEG_AMD_AMP_DTYPE): the 16-bit type of the AMP mode cfg.dist.fp16 switches on.  "fp16" is
+        the reference's own mode - torch.cuda.amp.autocast() + a live GradScaler (clip_runner.py:226-230, core/hooks/optimizer.py:73-82):
+        scaled loss, unscale + overflow check + skipped steps, scale growth / back-off, the scaler's state in the checkpoint.  bf16 needs
+        no loss scale (fp32's exponent range): the scaler then runs disabled, as an identity."""
         self.model, self.net, self.cfg = model, net or model, cfg
+        amp = str(amp_dtype or os.environ.get("SIMSEG_AMD_AMP_DTYPE", "bf16")).lower().replace("torch.", "")
+        if amp not in ("bf16", "bfloat16", "fp16", "float16", "half"):
+            raise ValueError(f"amp_dtype {amp!r}: bf16 or fp16")
+        self.amp_dtype = torch.float16 if amp in ("fp16", "float16", "half") else torch.bfloat16
+        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(cfg.dist.fp16) and self.amp_dtype == torch.float16)
         groups = param_groups(model, cfg)
         p = dict(cfg.optim.param)
         if cfg.optim.name.endswith("AdamW"):
             self.optimizer = AdamW(groups, lr=cfg.optim.lr.init, betas=tuple(p.get("betas", (0.9, 0.999))), eps=p.get("eps", 1e-8),
-                                   weight_decay=p.get("weight_decay", 1e-2))
+                                   weight_decay=p.get("weight_decay", 1e-2), half_dtype=self.amp_dtype)
         else:
             import importlib
             mod, _, cls = cfg.optim.name.rpartition(".")
@@ -88,14 +98,15 @@ class Trainer:
     def train_step(self, batch):
         lrs = self.set_lrs(self.step)
         self.optimizer.zero_grad(set_to_none=self.net is self.model)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.cfg.dist.fp16)):
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=bool(self.cfg.dist.fp16)):
             loss_dict, i2t_acc, t2i_acc = self.net(batch)
         loss = sum(loss_dict.values())
-        loss.backward()
+        self.scaler.scale(loss).backward()           # (disabled scaler: the loss itself)
         clip = dict(self.cfg.optim.grad_clip)
-        if clip:
+        if clip:                                     # the reference clips BEFORE scaler.step (on the scaled gradients): core/hooks/optimizer.py:82-86
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None], **clip)
-        self.optimizer.step()
+        self.scaler.step(self.optimizer)             # unscale_, skip the step on inf / nan (disabled: optimizer.step())
+        self.scaler.update()
         self.step += 1
         self.inner_step += 1
         return {"loss": loss.detach(), "i2t_acc": i2t_acc, "t2i_acc": t2i_acc, "lr": lrs[0]}
@@ -105,7 +116,7 @@ class Trainer:
         meta = dict(time=time.asctime(), simseg_version="0.1.0+mi355x", torch_version=torch.__version__,
                     epoch=self.epoch + 1 if end_of_epoch else self.epoch, step=self.step, inner_step=0 if end_of_epoch else self.inner_step)
         return dict(state_dict=self.model.state_dict(), optimizer=self.optimizer.state_dict(), meta=meta,
-                    scaler=torch.amp.GradScaler("cuda", enabled=False).state_dict())
+                    scaler=self.scaler.state_dict())
 
     def load_checkpoint(self, state, load_optimizer=True):
         sd = state.get("state_dict") or state.get("model_state_dict") or state.get("model")      # tasks/clip/hooks/checkpoint.py:58-76
@@ -114,6 +125,8 @@ class Trainer:
         if load_optimizer and "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
             self.optimizer._plans.clear() if hasattr(self.optimizer, "_plans") else None
+        if self.scaler.is_enabled() and state.get("scaler"):
+            self.scaler.load_state_dict(state["scaler"])
         meta = state.get("meta", {})
         self.step, self.epoch, self.inner_step = meta.get("step", 0), meta.get("epoch", 0), meta.get("inner_step", 0)
         return missing, unexpected

@@ -85,6 +85,27 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"null operand" in l.simseg_last_error()
 
 
+def test_fp16_flavour_is_built_selectable_and_its_rename_header_is_current():
+    """The 16-bit sources are compiled twice (bf16 as they stand, fp16 with -DSS_HALF); csrc/half_names.h - generated from the sources'
+    entry points and the public header's prototypes - is the committed, current generation; every renamed twin is exported; the
+    selector validates its argument and forwards (callable without a GPU: argument checks come before any device work)."""
+    import os
+    from simseg_amd import build, lib
+    text = build.gen_half_names(write=False)
+    assert open(os.path.join(build.CSRC, "half_names.h")).read() == text, "csrc/half_names.h is stale: python -m simseg_amd.build"
+    so = ctypes.CDLL(lib.LIB_PATH)
+    twins = [ln.split()[2] for ln in text.splitlines() if ln.startswith("#define ")]
+    assert len(twins) >= 30 and all(t.endswith("_h16") and hasattr(so, t) for t in twins)
+    l = lib.load()
+    assert l.simseg_set_half_type(3) != 0 and b"simseg_set_half_type" in l.simseg_last_error()
+    assert l.simseg_set_half_type(2) == 0
+    try:        # the bf16 entry hands the call to its fp16 twin, whose own argument check answers
+        assert l.simseg_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1.0, None, None, None, 0, 0, None, None, 0, 0, 0, 1, 0, 0.0, None, None) != 0
+        assert b"null operand" in l.simseg_last_error()
+    finally:
+        assert l.simseg_set_half_type(1) == 0
+
+
 def test_interpolate_pos_embed_and_miou_match_reference(golden):
     import types
     import numpy as np
