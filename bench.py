@@ -631,6 +631,39 @@ def main():
         finally:
             os.environ["SIMSEG_AMD_PACKED_TEXT"] = "1"
 
+    # ---- the same step in the reference's own AMP type: fp16 compute + a live GradScaler (clip_runner.py:226-230, core/hooks/
+    # optimizer.py:73-82) - the fp16 flavour of the same kernels (secondary figure, same process; single-rank runs only: the scaler's
+    # skip decision is per rank)
+    fp16_amp = None
+    if world == 1 and os.environ.get("SIMSEG_BENCH_FP16", "1") != "0":
+        os.environ["SIMSEG_AMD_COMPUTE"] = "fp16"
+        opt.half_dtype = torch.float16            # the optimizer kernel's 16-bit weight copies follow the compute type
+        opt._plans.clear()
+        scaler = torch.amp.GradScaler("cuda")     # torch's defaults, as the reference constructs it: scale 65536, back-off 0.5, growth every 2000 clean steps
+        try:
+            def step16():
+                opt.zero_grad(set_to_none=True)
+                loss_dict, _, _ = net(next_batch())
+                scaler.scale(loss_dict["nce_loss"]).backward()
+                scaler.step(opt)
+                scaler.update()
+            for _ in range(max(3, args.warmup)):
+                step16()
+            torch.cuda.synchronize()
+            skipped0 = opt._step
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step16()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t2
+            fp16_amp = {"pairs_per_s": round(B * args.steps / el3, 2), "ms_per_step": round(1e3 * el3 / args.steps, 3),
+                        "loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt._step - skipped0, "steps": args.steps,
+                        "note": "torch.amp.GradScaler live: scaled backward, unscale + inf check (one host read per step), skipped steps on overflow"}
+        finally:
+            os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+            opt.half_dtype = torch.bfloat16
+            opt._plans.clear()
+
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
     # The timed steps run the two towers on two HIP streams (their kernels share the GPU, so a per-kernel duration is not
     # that kernel's own speed); the instrumented step runs them on ONE stream so that each launch is timed alone.
@@ -755,7 +788,7 @@ def main():
                            "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4),
-                           "with_padded_caption_tokens_computed": dense_text},
+                           "with_padded_caption_tokens_computed": dense_text, "fp16_amp_with_gradscaler": fp16_amp},
             "seg_eval": seg,
             "retrieval_eval": retr,
             "cpu_baseline": cpu,

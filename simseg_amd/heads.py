@@ -164,10 +164,22 @@ def patch_text_similarity(patch_proj, text_feat, eps=1e-12, compute_dtype=F32):
     return ops.gemm(x, t, rowscale=rn, out_dtype=F32).view(B, N, t.shape[0])
 
 
+def _similarity_matrix(left, right):
+    """left @ right^T in fp32 (the reference's torch.matmul of the gathered embeddings, tasks/clip/hooks/utils.py:36).  Large problems - the
+    5000 x 25000 x 512 matrix of the MSCOCO-5k evaluation - go through the split-bf16 form of the fp32 product (towers._fwd_gemm: six
+    bf16 piece products in one MFMA launch, fp32-grade accuracy) instead of the fp32 MFMA kernel."""
+    from . import towers
+    a, b = left.contiguous().float(), right.contiguous().float()
+    if towers._split_ok(a.shape[0], b.shape[0], a.shape[1]):
+        towers.SPLIT_CALLS[0] += 1
+        return ops.gemm(ops.split_bf16x3(a), ops.split_bf16x3(b, b_pattern=True), out_dtype=F32)
+    return ops.gemm(a, b)
+
+
 def retrieval_recalls(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
     """R@k of `left` rows retrieving `right` rows sharing their group id (hooks/utils.py:59-75).  One host sync
     (4 counters), like the reference's .item()."""
-    sim = ops.gemm(left.contiguous().float(), right.contiguous().float())
+    sim = _similarity_matrix(left, right)
     has, rank = ops.retrieval_rank(sim, left_gid.contiguous().long(), right_gid.contiguous().long())
     c = ops.recall_counts(has, rank, bounds).cpu()
     if int(c[0]) == 0:
@@ -179,7 +191,7 @@ def retrieval_recalls_both(left, left_gid, right, right_gid, bounds=(1, 5, 10)):
     """Both directions of the retrieval evaluation (tools/retrieval_evaluation.py:33-40 calls the metric twice with swapped arguments)
     from ONE similarity matrix: rows rank their columns, columns rank their rows.  Returns (left->right, right->left)."""
     lg, rg = left_gid.contiguous().long(), right_gid.contiguous().long()
-    sim = ops.gemm(left.contiguous().float(), right.contiguous().float())
+    sim = _similarity_matrix(left, right)
     has, rank = ops.retrieval_rank(sim, lg, rg)
     hasc, rankc = ops.retrieval_rank_cols(sim, lg, rg)
     c = torch.stack([ops.recall_counts(has, rank, bounds), ops.recall_counts(hasc, rankc, bounds)]).cpu()
