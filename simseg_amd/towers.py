@@ -116,6 +116,8 @@ def _saving(ctx):
     """Does this forward need to keep anything for a backward?  Under torch.no_grad() - every evaluation tool - the parameters still
     'need' gradients as far as ctx.needs_input_grad is concerned, and the blocks used to save statistics, log-sum-exps and GELU
     derivatives nobody would read."""
+    if os.environ.get("SIMSEG_AMD_EVAL_SAVES") == "1":      # A/B runs: the round-2 behaviour (evaluation forwards save as training ones do)
+        return any(ctx.needs_input_grad)
     return getattr(_GRAD_MODE, "on", True) and any(ctx.needs_input_grad)
 
 
