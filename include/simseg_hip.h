@@ -196,10 +196,15 @@ int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream)
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);
 /* fp32 [rows, K] (row stride ld_in) -> bf16 [rows, 6 K]: the three round-to-nearest bf16 pieces hi / mid / lo of every element
  * (hi + mid + lo == x), laid out along K as [hi|hi|hi|mid|mid|lo] (b_pattern = 0, the A operand) or [hi|mid|lo|hi|mid|hi] (b_pattern = 1,
- * the B operand), so that ONE simseg_gemm call on the two bf16 images forms the six leading piece products of the fp32 product in its
+ * the B operand; b_pattern = 2: three planes bf16 [3][rows, K] instead, the operand form of simseg_attention_fwd_x3), so that ONE simseg_gemm call on the two bf16 images forms the six leading piece products of the fp32 product in its
  * fp32 accumulators - the exact-mode nn.Linear of the evaluation tools (torch fp32 matmul, vit_builder.py:18 / huggingface_builder.py:16-17
  * without autocast) at the bf16 MFMA rate; the three dropped products are <= 2^-24 |a||b|, the size of an fp32 FMA's own rounding. */
 int simseg_split_bf16x3(const float* in, void* out, int64_t rows, int64_t K, int64_t ld_in, int b_pattern, void* stream);
+/* Exact-mode attention forward (timm Attention.forward in fp32, vit_builder.py:18, as the evaluation tools run it) on the bf16 matrix pipe:
+ * qkv3 = the three bf16 pieces of the fp32 packed projection as planes (simseg_split_bf16x3 with b_pattern = 2: bf16 [3][B, T, 3, H, 64],
+ * piece p at qkv3 + p * plane_elems); scores and outputs accumulate the six leading piece products in fp32 (fp32-grade accuracy, like
+ * the split GEMM).  out fp32 [B, T, H*64].  No mask / dropout / log-sum-exp: evaluation only. */
+int simseg_attention_fwd_x3(const void* qkv3, int64_t plane_elems, float* out, int64_t B, int64_t T, int64_t H, float scale, void* stream);
 /* dst[i,:] = src[idx[i],:] (idx[i] < 0: a zero row); rows of row_bytes (a multiple of 16) bytes, any dtype.  Drops / restores the padded
  * token rows of ragged caption batches around the text tower's GEMMs (HF BertModel computes them: huggingface_builder.py:16-17). */
 int simseg_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t row_bytes, void* stream);

@@ -153,7 +153,7 @@ def _two_streams_ok():
 def _side_stream(device):
     st = _SIDE.get(device)
     if st is None:
-        st = _SIDE[device] = torch.cuda.Stream(device=device)
+        st = _SIDE[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("SIMSEG_AMD_SIDE_PRIORITY", "0")))      # (A/B: -1 = the text tower's stream at high priority)
         # text-tower gradients are produced on the side stream and accumulated on the parameters' stream: intended
         # (autograd inserts the synchronisation), so its advisory warning is switched off
         f = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)

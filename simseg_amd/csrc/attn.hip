@@ -507,6 +507,16 @@ constexpr int MAXT_BIAS = 1088;          // key-bias table of a masked sequence 
 __device__ __forceinline__ int k_swz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int v_swz(int r) { return ((r >> 1) & 1) << 2; }
 
+// One global -> LDS copy (16 B per lane, 1 KiB per wave) issued from inline asm.  Through the builtin the compiler knows that LDS
+// writes are in flight and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint - in these ring kernels the
+// transposed V reads of the SAME iteration that issued the copies of a tile two ahead: the copies' whole latency then sat inside every
+// tile (found in the ISA of the exact-mode kernel: 0.49 of its 1.33 ms).  Issued this way they are invisible to the compiler's wait
+// counting; the kernels' own vmcnt waits at the tile barriers are the only ones.  lds_dst: wave-uniform LDS byte address (M0).
+__device__ __forceinline__ void glds16_asm(const void* src, char* lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory");
+}
+
 // this wave's share of one tile: pieces 0..7 = K rows, 8..15 = V rows; every wave issues exactly `per` instructions so
 // the vmcnt bookkeeping is uniform (surplus ones repeat piece 15: same bytes to the same place)
 __device__ __forceinline__ void kv_glds(const bf16_t* base, long RS, int HD, int kv0, int T, char* stage, int wave, int nw, int per,
@@ -520,8 +530,7 @@ __device__ __forceinline__ void kv_glds(const bf16_t* base, long RS, int HD, int
         int key = kv0 + r;
         key = key < T ? key : T - 1;
         const bf16_t* src = base + (long)key * RS + (isv + 1) * HD + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + piece * 1024), 16, 0, 0);
+        glds16_asm(src, stage + piece * 1024);
     }
 }
 
@@ -703,6 +712,190 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         d[8 + blin * 4 + 1] = tend;
         d[8 + blin * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
         d[8 + blin * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Exact-mode forward on the bf16 matrix pipe (round 3): softmax(Q K^T) V of fp32 q / k / v with every product formed from the three
+// exact bf16 pieces of its operands (simseg_split_bf16x3, planes form: hi / mid / lo of the packed qkv rows).  An fp32 product is nine
+// piece products; the three smallest (<= 2^-24 |a||b|, an fp32 FMA's own rounding) are dropped: S accumulates (q_hi + q_mid + q_lo) k_hi
+// + (q_hi + q_mid) k_mid + q_hi k_lo in fp32, the fp32 probabilities are split in registers and O accumulates the same six
+// combinations of P and V pieces.  Six times the MFMA work of the bf16 kernel at sixteen times the fp32 MFMA rate: the kernel is
+// MFMA-bound where the bf16 kernel is softmax-VALU-bound.  Structure of attn_fwd_bf16_kernel: 64-key tiles global -> LDS directly into
+// a ring of three stages two tiles ahead ([K hi | K mid | K lo | V hi | V mid | V lo], 48 KiB per stage: one 8-wave block per CU),
+// one barrier per tile, swapped S^T = K Q^T, lean online softmax.  Evaluation only: no mask, no dropout, no log-sum-exp.
+// ------------------------------------------------------------------------------------------------
+constexpr int X3_STAGE = 6 * KT * 128;
+constexpr int X3_NS = 3;
+
+struct AttnX3Params { const bf16_t* qkv3; long plane; float* out; int B, T, H; float scale_log2e; int dbg; };
+
+__device__ __forceinline__ void kv_glds_x3(const bf16_t* base, long plane, long RS, int HD, int kv0, int T, char* stage, int wave, int nw, int per,
+                                           int lane) {
+    for (int i = 0; i < per; ++i) {                    // 48 pieces of 1 KiB per tile; every wave issues `per` (surplus ones repeat piece 47)
+        int piece = wave + i * nw;
+        piece = piece < 48 ? piece : 47;
+        const int sel = piece >> 3;                    // 0..2: K hi / mid / lo, 3..5: V hi / mid / lo
+        const int isv = sel >= 3, pc = isv ? sel - 3 : sel;
+        const int r = (piece & 7) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (isv ? v_swz(r) : k_swz(r));
+        int key = kv0 + r;
+        key = key < T ? key : T - 1;
+        const bf16_t* src = base + pc * plane + (long)key * RS + (isv + 1) * HD + c * 8;
+        glds16_asm(src, stage + piece * 1024);
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_x3_kernel(AttnX3Params p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    const int nw = blockDim.x >> 6, per = (48 + nw - 1) / nw;
+    // block -> (head, query block of nw x 32 rows): consecutive ids go to consecutive XCDs; all blocks of a head share a residue
+    const int gx = ((p.T + 31) / 32 + nw - 1) / nw;
+    const int L = blockIdx.x, slot = L >> 3;
+    const int bh_ = (slot / gx) * 8 + (L & 7), qb_ = slot % gx;
+    if (bh_ >= p.B * p.H) return;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64;
+    const bf16_t* base = p.qkv3 + (long)b * T * RS + h * 64;
+    const int q = (qb_ * nw + wave) * 32 + ql;
+    const bool active = (qb_ * nw + wave) * 32 < T;         // (wave-uniform; a padding wave still copies and meets the barriers)
+    const int HD = p.H * 64;
+    const int nt = (T + KT - 1) / KT;
+    bf16x8 qr[3][4];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { u32x4 v; bf16x8 hh; } u;
+            u.v = *reinterpret_cast<const u32x4*>(base + pc * p.plane + (long)min(q, T - 1) * RS + (2 * kk + h2) * 8);     // (queries >= T: row T-1, never stored)
+            qr[pc][kk] = u.hh;
+        }
+    kv_glds_x3(base, p.plane, RS, HD, 0, T, lds, wave, nw, per, lane);
+    if (nt > 1) kv_glds_x3(base, p.plane, RS, HD, KT, T, lds + X3_STAGE, wave, nw, per, lane);
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = NEG, lsum = 0.f;
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int krow = ql * 128, ksw = k_swz(ql);
+    const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
+    const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
+    // S^T of one tile: K_pc times the Q pieces whose product with it is kept (lo with hi only, mid with hi / mid, hi with all three),
+    // smallest terms first
+    auto scores = [&](const char* sk, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {
+            bf16x8 kf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = ld_bf16x8(sk + pc * (KT * 128) + (i >> 2) * 32 * 128 + krow + (((2 * (i & 3) + h2) ^ ksw) << 4));
+#pragma unroll
+            for (int qp = 2; qp >= 0; --qp) {
+                if (qp + pc > 2) continue;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s[0] = SS_MFMA_32x32x16(kf[kk], qr[qp][kk], s[0], 0, 0, 0);
+                    s[1] = SS_MFMA_32x32x16(kf[4 + kk], qr[qp][kk], s[1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // Software pipeline inside the wave: the scores of tile it + 1 are issued BEFORE the softmax of tile it, so the matrix pipe works
+    // through 48 MFMAs while the VALU forms the exponentials and the three pieces of P (every wave of the block passes the tile
+    // barrier at the same time: without this the two waves of a SIMD do their MFMA phases together and their VALU phases together).
+    // Tiles it and it + 1 are resident when iteration `it` starts; the stage of tile it - 1 is refilled with tile it + 2.
+    f32x16 s[2], sn[2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // Q and this wave's copies of tiles 0 / 1
+    __builtin_amdgcn_s_barrier();
+    if (active) scores(lds, s);
+    int cur = 0;
+    auto tile = [&](int it, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int kv0 = it * KT;
+        if (it > 0 && !(p.dbg & 16)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies of tile it + 1 (issued one iteration ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (it + 2 < nt && !(p.dbg & 8)) {                  // every wave has left tile it - 1: its stage takes tile it + 2
+            int ns = cur + 2; ns = ns >= X3_NS ? ns - X3_NS : ns;
+            kv_glds_x3(base, p.plane, RS, HD, kv0 + 2 * KT, T, lds + ns * X3_STAGE, wave, nw, per, lane);
+        }
+        if (!active) { cur = cur + 1 == X3_NS ? 0 : cur + 1; return; }
+        const char* sv = lds + cur * X3_STAGE + 3 * KT * 128;
+        int nx = cur + 1; nx = nx == X3_NS ? 0 : nx;
+        // The two waves of a SIMD (w and w + 4) run the tile's three stages in DIFFERENT orders - the first group scores(next), softmax,
+        // PV; the second softmax, PV, scores(next) - so that one's exponential / piece arithmetic (VALU) runs beside the other's MFMAs:
+        // every wave passes the tile barrier at the same instant, and with one order both waves of a SIMD held the matrix pipe together
+        // and then the VALU together (MFMA time + VALU time per tile, measured).
+        const bool first = wave < 4;
+        if (!EDGE && first && !(p.dbg & 4)) scores(lds + nx * X3_STAGE, sn);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 1)) softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0);
+        // the fp32 probabilities as three exact bf16 pieces (index [piece][kb * 2 + s2])
+        bf16x8 pp[3][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = s[kb][8 * s2 + e];
+                    const bf16_t hi = (bf16_t)x;
+                    const float r1 = x - (float)hi;
+                    const bf16_t mid = (bf16_t)r1;
+                    pp[0][kb * 2 + s2][e] = hi;
+                    pp[1][kb * 2 + s2][e] = mid;
+                    pp[2][kb * 2 + s2][e] = (bf16_t)(r1 - (float)mid);
+                }
+        if (!(p.dbg & 2))
+#pragma unroll
+        for (int vc = 2; vc >= 0; --vc) {
+            bf16x8 vf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {     // i = kb*4 + s2*2 + db
+                const int roff = ((i >> 2) * 32 + 16 * ((i >> 1) & 1)) * 128 + vrow;
+                const int coff = ((((i & 1) * 4 + vch) ^ vsw) << 4) + vsub;
+                vf[i] = tr_frag(sv + vc * (KT * 128) + roff + coff, 8 * 128);
+            }
+#pragma unroll
+            for (int pq = 2; pq >= 0; --pq) {
+                if (pq + vc > 2) continue;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+                            o[db] = SS_MFMA_32x32x16(vf[kb * 4 + s2 * 2 + db], pp[pq][kb * 2 + s2], o[db], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!EDGE && !first && !(p.dbg & 4)) scores(lds + nx * X3_STAGE, sn);
+        if (!EDGE) { s[0] = sn[0]; s[1] = sn[1]; }
+        cur = cur + 1 == X3_NS ? 0 : cur + 1;
+    };
+    for (int it = 0; it < nt - 1; ++it) tile(it, std::false_type{});
+    tile(nt - 1, std::true_type{});
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (q < T) {
+        float* orow = p.out + ((long)b * T + q) * p.H * 64 + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = db * 32 + 8 * r4 + 4 * h2;
+                *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * r4] * inv, o[db][4 * r4 + 1] * inv, o[db][4 * r4 + 2] * inv, o[db][4 * r4 + 3] * inv);
+            }
     }
 }
 
@@ -2040,6 +2233,37 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     SS_LAUNCH_CHECK("attention_fwd");
     return 0;
 }
+
+// Exact-mode attention forward through the bf16 pieces of the fp32 operands (attn_fwd_x3_kernel).  qkv3: bf16 [3 pieces][B, T, 3, H, 64]
+// (simseg_split_bf16x3 with b_pattern = 2 of the fp32 packed projection), piece p at qkv3 + p * plane_elems; out fp32 [B, T, H * 64].
+extern "C" int simseg_attention_fwd_x3(const void* qkv3, int64_t plane_elems, float* out, int64_t B, int64_t T, int64_t H, float scale, void* stream) {
+    SS_CHECK(qkv3 && out, "attention_fwd_x3: null pointer");
+    SS_CHECK(B > 0 && T > 0 && H > 0 && B * H < 65536 * 16 && plane_elems >= B * T * 3 * H * 64, "attention_fwd_x3: bad shape");
+    SS_CHECK(((uintptr_t)qkv3 % 16) == 0 && ((uintptr_t)out % 16) == 0 && plane_elems % 8 == 0, "attention_fwd_x3: operands must be 16-byte aligned");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_NS * X3_STAGE);
+        if (e != hipSuccess) return simseg_set_error("attention_fwd_x3: cannot reserve LDS: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    AttnX3Params p;
+    p.qkv3 = static_cast<const bf16_t*>(qkv3); p.plane = (long)plane_elems; p.out = out; p.B = (int)B; p.T = (int)T; p.H = (int)H;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    p.dbg = g_attn_variant >= 200 ? g_attn_variant - 200 : 0;      // (timing ablations, WRONG results: tools/attn_x3_bench.py)
+    // waves (32-query tiles) per block: 4..8, the count that leaves the fewest padding waves in a head's last block (33 tiles at
+    // T = 1025: five blocks of 7; 11 at T = 325: two of 6); ties go to the larger block
+    const int q32 = (int)((T + 31) / 32);
+    int nw = q32 < 4 ? (q32 < 1 ? 1 : q32) : 4, best = 1 << 30;
+    for (int c = 4; c <= 8 && q32 >= 4; ++c) {
+        const int padded = ((q32 + c - 1) / c) * c;
+        if (padded <= best) { best = padded; nw = c; }
+    }
+    const int gx = (q32 + nw - 1) / nw;
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3((unsigned)(gx * (((B * H + 7) / 8) * 8))), dim3(nw * 64), X3_NS * X3_STAGE, (hipStream_t)stream, p);
+    SS_LAUNCH_CHECK("attention_fwd_x3");
+    return 0;
+}
+
 
 // debug: forward with a cycle-counter timeline of block (0,0) / thread 0 written to dbg[0..4] (5 x u64):
 // {first tile staging, S = K.Q^T, softmax + rescale, P.V, next-tile commit + barriers}, summed over the K/V tiles

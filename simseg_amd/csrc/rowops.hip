@@ -612,6 +612,13 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
             mid.h[e] = (bf16_t)r1;
             lo.h[e] = (bf16_t)(r1 - (float)mid.h[e]);
         }
+        if (bpat == 2) {                                 // three planes [piece][row][K] (the attention kernel's operand form)
+            bf16_t* o = out + r * (long)K + k0;
+            *reinterpret_cast<u32x4*>(o) = hi.v;
+            *reinterpret_cast<u32x4*>(o + rows * (long)K) = mid.v;
+            *reinterpret_cast<u32x4*>(o + 2 * rows * (long)K) = lo.v;
+            continue;
+        }
         bf16_t* o = out + r * (6L * K) + k0;
         // A pattern: hi hi hi mid mid lo;  B pattern: hi mid lo hi mid hi
         *reinterpret_cast<u32x4*>(o) = hi.v;

@@ -278,7 +278,21 @@ def cast(x, dtype, out=None):
     return out
 
 
-def split_bf16x3(x2d, b_pattern=False):
+def attention_fwd_x3(qkv32, heads, scale=0.125):
+    """Exact-mode attention forward on the bf16 matrix pipe: qkv32 fp32 [B, T, 3*H*64] -> ctx fp32 [B, T, H*64], every product formed from
+    the three exact bf16 pieces of its fp32 operands (six leading piece products, fp32 accumulation: include/simseg_hip.h).  Evaluation
+    only (no mask, dropout or saved log-sum-exp)."""
+    require_gpu(qkv32)
+    B, T, W = qkv32.shape
+    if qkv32.dtype != torch.float32 or W != 3 * heads * 64:
+        raise ValueError("attention_fwd_x3: fp32 [B, T, 3*H*64]")
+    planes = split_bf16x3(_c(qkv32).view(B * T, W), planes=True)           # [3, B*T, W]
+    out = torch.empty(B, T, heads * 64, device=qkv32.device, dtype=torch.float32)
+    call("simseg_attention_fwd_x3", ptr(planes), B * T * W, ptr(out), B, T, heads, float(scale), stream())
+    return out
+
+
+def split_bf16x3(x2d, b_pattern=False, planes=False):
     """fp32 [rows, K] -> bf16 [rows, 6 K]: the hi / mid / lo bf16 pieces of every element along K, in the A-operand order (hi hi hi mid mid
     lo) or the B-operand order (hi mid lo hi mid hi): gemm(split(a), split(b, True)) is the fp32 product a @ b^T formed on the bf16 MFMA
     pipe in fp32 accumulators (include/simseg_hip.h: simseg_split_bf16x3)."""
@@ -286,8 +300,9 @@ def split_bf16x3(x2d, b_pattern=False):
     rows, K = x2d.shape
     if x2d.stride(1) != 1:
         raise ValueError("split_bf16x3 needs unit-stride rows")
-    out = torch.empty(rows, 6 * K, device=x2d.device, dtype=torch.bfloat16)
-    call("simseg_split_bf16x3", ptr(x2d), ptr(out), rows, K, x2d.stride(0), int(bool(b_pattern)), stream())
+    # planes: the three pieces as [3, rows, K] (operand form of attention_fwd_x3) instead of the six K-segments of the GEMM operands
+    out = torch.empty((3, rows, K) if planes else (rows, 6 * K), device=x2d.device, dtype=torch.bfloat16)
+    call("simseg_split_bf16x3", ptr(x2d), ptr(out), rows, K, x2d.stride(0), 2 if planes else int(bool(b_pattern)), stream())
     return out
 
 

@@ -353,7 +353,14 @@ class ViTBlockFn(_GradAwareFn):
         ln1, _, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), 1e-6, out_dtype=adt, save_stats=save)
         if not save:        # evaluation: no operand is kept (exact mode: large problems go through the split-bf16 form of the fp32 products)
             qkv = _fwd_gemm(ln1.view(-1, D), qw, adt, False, bias=qb.detach())
-            att, _ = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=False)
+            if adt == F32 and _SPLIT_FP32 != "0" and (_SPLIT_FP32 == "1" or (T >= 512 and B * heads >= 128)):
+                # exact mode, long sequences: the attention products through the bf16 pieces as well (the fp32 MFMA kernel is 20 % of an
+                # exact-mode ViT-B@512 evaluation once the GEMMs are split; measured 2.07 -> 1.58 ms per layer at 63 x 1025 tokens with the
+                # split pass, a tie at T = 325, slower at T = 197: tools/attn_x3_bench.py)
+                SPLIT_CALLS[0] += 1
+                att = ops.attention_fwd_x3(qkv.view(B, T, 3 * D), heads, scale=64 ** -0.5)
+            else:
+                att, _ = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=False)
             x1 = _fwd_gemm(att.view(-1, D), pw, adt, False, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
             ln2, _, _, _ = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=False)
             act = _fwd_gemm(ln2, f1w, adt, False, bias=f1b.detach(), act=1)

@@ -68,7 +68,7 @@ def test_vit_tower_through_split_gemms_matches_fp32_kernels_and_oracle(monkeypat
         monkeypatch.setattr(towers, "_SPLIT_FP32", "1")
         n0 = towers.SPLIT_CALLS[0]
         split = m(x.cuda())
-        assert towers.SPLIT_CALLS[0] - n0 == 1 + 4 * 12          # patch embedding + four linear layers per block
+        assert towers.SPLIT_CALLS[0] - n0 == 1 + 5 * 12          # patch embedding + four linear layers and the attention per block
     scale = float(want.abs().max())
     e_native = float((native.cpu() - want).abs().max()) / scale
     e_split = float((split.cpu() - want).abs().max()) / scale
@@ -81,3 +81,22 @@ def test_vit_tower_through_split_gemms_matches_fp32_kernels_and_oracle(monkeypat
     xg = x[:2].cuda()
     m(xg).sum().backward()
     assert towers.SPLIT_CALLS[0] == n0
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 1025, 12), (3, 325, 6), (2, 197, 4), (1, 64, 2), (1, 40, 1)])
+def test_attention_through_bf16_pieces_is_fp32_accurate(B, T, H):
+    """simseg_attention_fwd_x3 against the fp64 softmax(Q K^T / 8) V, next to the fp32 MFMA kernel on the same inputs."""
+    from simseg_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn(B, T, 3 * H * 64, device="cuda", generator=g) * 1.5
+    qkv[0, 0] *= 6.0                                          # a row with large scores: sharp softmax, a raised running maximum
+    q, k, v = [t.view(B, T, H, 64).transpose(1, 2).double() for t in qkv.chunk(3, -1)]
+    want = ((q @ k.transpose(-1, -2) * 0.125).softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+    native, _ = ops.attention_fwd(qkv, H, None, scale=0.125)
+    got = ops.attention_fwd_x3(qkv, H, scale=0.125)
+    scale = float(want.abs().max())
+    e_native = float((native.double() - want).abs().max()) / scale
+    e_x3 = float((got.double() - want).abs().max()) / scale
+    print(f"B={B} T={T} H={H}: max |err| / max|out|  fp32 MFMA kernel {e_native:.2e}   bf16 pieces {e_x3:.2e}")
+    assert torch.isfinite(got).all()
+    assert e_x3 < 2e-6 and e_x3 < 4 * e_native + 2e-7
