@@ -164,7 +164,8 @@ def topk_pool_l2norm_fwd(tok, k, mask=None, eps=1e-8, normalize=True):
     idx = torch.empty(B, k, P, device=tok.device, dtype=torch.int32)
     norm = torch.empty(B, device=tok.device, dtype=torch.float32)
     scratch = None
-    if B < 64 and N >= 256:          # few images: scan token slices in parallel (one block per image would leave the GPU empty)
+    if B <= 256 and N >= 256:        # long token axes: scan 32 token slices per image in parallel, then merge (tools/pool_bench.py, N = 1024: 141 vs
+                                     # 522 us at B = 63, 244 vs 600 us at B = 128; one block per image walks its tokens serially)
         scratch = torch.empty(raw("simseg_topk_pool_workspace_bytes", B, P, int(k)) // 4, device=tok.device, dtype=torch.float32)
     call("simseg_topk_pool_l2norm_fwd", ptr(_c(tok)), dt(tok), ptr(_c(mask)), ptr(emb), ptr(idx), ptr(norm), ptr(scratch), B, N, P, int(k),
          float(eps), int(normalize), stream())
