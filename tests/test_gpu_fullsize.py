@@ -159,7 +159,10 @@ def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
         l16, _, _ = ref.forward_loss_local(image, ids, mask)
     l16.backward()
     yard = {n: _cos(p.grad, g32[n]) for n, p in ref.named_parameters()}
-    for two in ("0", "1"):
+    # (round 3: the same step once more in the fp16 flavour - the reference's own AMP type - under the loss scale its GradScaler starts from)
+    for mode, two in (("bf16", "0"), ("bf16", "1"), ("fp16", "1")):
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+        scale = 65536.0 if mode == "fp16" else 1.0
         monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", two)
         m = _build_vitb(224)
         missing, unexpected = m.load_state_dict(ref.state_dict(), strict=False)
@@ -167,7 +170,7 @@ def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
         m = m.cuda().eval()                                      # eval: no dropout, so gradients are comparable
         # the batch is a temporary: its device tensors die with the forward call unless the model keeps them alive correctly
         loss = m({"image": image.cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})[0]["nce_loss"]
-        loss.backward()
+        (loss * scale).backward()
         torch.cuda.synchronize()
         assert abs(loss.item() - want.item()) < 1e-2 * abs(want.item()), (loss.item(), want.item())
         worst_c, worst_r, bad, null = 1.0, 0.0, [], []
@@ -175,6 +178,7 @@ def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
             gr = g32[n]
             assert p.grad is not None, n
             assert torch.isfinite(p.grad).all(), n
+            p.grad.div_(scale)
             if float(gr.norm()) < 1e-6:
                 assert n.endswith("attention.self.key.bias"), (n, float(gr.norm()))
                 rel = float(p.grad.float().norm()) / float(g32[n.replace(".key.", ".value.")].norm())
@@ -187,7 +191,7 @@ def test_vitb_bertbase_train_step_gradients_vs_oracle(monkeypatch):
             worst_c, worst_r = min(worst_c, c), max(worst_r, abs(r - 1))
             if not (c >= 0.985 and abs(r - 1) <= 0.03 and (1 - c) <= max(1 - yard[n], 1e-3)):
                 bad.append((n, round(c, 5), round(r, 4), "autocast yardstick", round(yard[n], 5)))
-        print(f"two_streams={two}: ViT-B/BERT-base bf16 gradients vs fp32 oracle: worst cosine {worst_c:.5f} (torch autocast-bf16 yardstick: "
+        print(f"two_streams={two}: ViT-B/BERT-base {mode} gradients vs fp32 oracle: worst cosine {worst_c:.5f} (torch autocast-bf16 yardstick: "
               f"worst {min(v for k, v in yard.items() if not k.endswith('key.bias')):.5f}), worst |norm ratio - 1| {worst_r:.4f}; "
               f"key-bias null-space size max {max(null):.2e}")
         for b_ in bad:
