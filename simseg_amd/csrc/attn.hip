@@ -507,14 +507,19 @@ constexpr int MAXT_BIAS = 1088;          // key-bias table of a masked sequence 
 __device__ __forceinline__ int k_swz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int v_swz(int r) { return ((r >> 1) & 1) << 2; }
 
-// One global -> LDS copy (16 B per lane, 1 KiB per wave) issued from inline asm.  Through the builtin the compiler knows that LDS
-// writes are in flight and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint - in these ring kernels the
-// transposed V reads of the SAME iteration that issued the copies of a tile two ahead: the copies' whole latency then sat inside every
-// tile (found in the ISA of the exact-mode kernel: 0.49 of its 1.33 ms).  Issued this way they are invisible to the compiler's wait
-// counting; the kernels' own vmcnt waits at the tile barriers are the only ones.  lds_dst: wave-uniform LDS byte address (M0).
+// One global -> LDS copy (16 B per lane, 1 KiB per wave) of the ring kernels.  Through the builtin the compiler knows that LDS writes are
+// in flight and puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint - in these kernels the transposed V reads
+// of the SAME iteration that issued the copies of a tile two ahead (visible in the ISA).  The inline-asm form (-DSS_GLDS_ASM) is invisible
+// to that wait counting, the kernels' own vmcnt waits at the tile barriers being the only ones - and measured NO better: exact-mode kernel
+// unchanged (1.33 ms), bf16 streaming forward at T = 1025 2.6 % slower (0.1010 vs 0.0983 ms, same-box A/B of two builds): by the time a
+// wave reaches its V reads the copies have had the scores and the softmax to land.  The builtin stays.
 __device__ __forceinline__ void glds16_asm(const void* src, char* lds_dst) {
+#ifndef SS_GLDS_ASM          // default: the compiler-visible form (-DSS_GLDS_ASM: A/B builds)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#else
     const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_dst);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory");
+#endif
 }
 
 // this wave's share of one tile: pieces 0..7 = K rows, 8..15 = V rows; every wave issues exactly `per` instructions so
