@@ -175,7 +175,59 @@ def _zeros(device, *shapes):
     return [buf[a:a + n].view(sh) for a, n, sh in zip(offs, sizes, shapes)]
 
 
+# Weight gradients on their own stream (opt-in experiment, SIMSEG_AMD_WGRAD_STREAM=1): a block's four weight-gradient GEMMs depend only on
+# tensors its backward already has and nothing reads their results before the optimizer, so they can run beside the data-gradient chain
+# (dgrad -> LayerNorm backward -> attention backward ...) instead of inside it.  One extra stream per stream the backward runs on (the two
+# towers have their own); joined before the block's backward returns.
+_WG_ON = os.environ.get("SIMSEG_AMD_WGRAD_STREAM", "0") == "1"
+_WG_STREAMS = {}
+_WG_PENDING = threading.local()
+
+
+def _wg_side(cur):
+    st = _WG_STREAMS.get(cur.cuda_stream)
+    if st is None:
+        st = _WG_STREAMS[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+    return st
+
+
+def _wg_join():
+    pend = getattr(_WG_PENDING, "streams", None)
+    if pend:
+        cur = torch.cuda.current_stream()
+        for st in pend:
+            cur.wait_stream(st)
+        pend.clear()
+
+
+def _joins_wgrad(fn):
+    def wrapped(ctx, *grads):
+        try:
+            return fn(ctx, *grads)
+        finally:
+            _wg_join()
+    return wrapped
+
+
 def _wgrad(dy, x, out=None):
+    if _WG_ON and dy.is_cuda:
+        cur = torch.cuda.current_stream()
+        side = _wg_side(cur)
+        if out is None:
+            out = torch.zeros(dy.shape[1], x.shape[1], device=dy.device, dtype=F32)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _wgrad_now(dy, x, out)
+        pend = getattr(_WG_PENDING, "streams", None)
+        if pend is None:
+            pend = _WG_PENDING.streams = []
+        if side not in pend:
+            pend.append(side)
+        return out
+    return _wgrad_now(dy, x, out)
+
+
+def _wgrad_now(dy, x, out=None):
     """dW[out,in] = dy^T . x  (contraction over rows), fp32, split-K atomics into the zero-filled `out`.  bf16 operands go to the
     transposed-operand MFMA kernel; fp32 operands (exact mode) are transposed first - the fp32 kernel is row.row only."""
     out_f, in_f = dy.shape[1], x.shape[1]
@@ -274,6 +326,7 @@ class LinearFn(_GradAwareFn):
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
+    @_joins_wgrad
     def backward(ctx, dy):
         xa, wa = ctx.saved_tensors
         d16 = _act_grad(dy.reshape(-1, dy.shape[-1]).contiguous(), ctx.adt)
@@ -323,6 +376,7 @@ class ViTEmbedFn(_GradAwareFn):
         return x
 
     @staticmethod
+    @_joins_wgrad
     def backward(ctx, dx):
         (cols,) = ctx.saved_tensors
         B, N, D = ctx.dims
@@ -380,6 +434,7 @@ class ViTBlockFn(_GradAwareFn):
         return y.view(B, T, D)
 
     @staticmethod
+    @_joins_wgrad
     def backward(ctx, dy):
         x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_, n1w, n2w = ctx.saved_tensors
         B, T, D = ctx.dims
@@ -590,6 +645,7 @@ class BertLayerFn(_GradAwareFn):
         return y if packed else y.view(B, L, D)
 
     @staticmethod
+    @_joins_wgrad
     def backward(ctx, dy):
         (xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_, law, low, attd, idx, inv, cu) = ctx.saved_tensors
         B, L, D = ctx.dims
@@ -714,6 +770,7 @@ class ProjectPoolFn(_GradAwareFn):
         return emb
 
     @staticmethod
+    @_joins_wgrad
     def backward(ctx, demb):
         fa, wa, emb, idx, norm = ctx.saved_tensors
         B, N, D = ctx.dims
