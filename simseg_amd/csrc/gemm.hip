@@ -890,51 +890,88 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     if (p.act == 4) {
-        // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major
-        // like the output: it takes the reverse trip - 16-byte row-major loads, staged [row][column], and ds_read_b64_tr_b16
-        // hands lane (column c) the 4 consecutive rows of each accumulator register group.  The loads of block i + 1 are
-        // requested before the stores of block i.
-        constexpr int PA = 144;                              // bytes per staged row (64 columns x 2 B + 16 B pad)
+        // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
+        // output, and `emit` hands every lane its results as 16-byte row pieces - the very pieces (same row, same eight columns) a 16-byte
+        // load of the saved tensor returns.  So the product is formed THERE, on the way out: eight bf16 x bf16 -> fp32 products per piece,
+        // rounded once more and stored.  No LDS trip for the saved tensor, no second pair of wave barriers per block (round 2 staged it
+        // row-major, read it back transposed into the accumulator layout and multiplied before the packing: 18.2 us of epilogue per tile
+        // against 4.2 us for the plain store - tools/dbg_gemm_trace.py).  The matmul result is rounded to the 16-bit type BEFORE the
+        // multiplication, as torch's autocast does (a 16-bit matmul output feeding GELU's backward).  The loads of block i + 1 are requested
+        // before the stores of block i.  Column sums: 32 per-lane partials (a lane's four column octets are the same in all four blocks),
+        // reduced over the 32 lanes that share them through the wave's scratch.
         const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux);
         const int trow = (g4 & 1) * 16 + a16;
         const bf16_t* arow = Ab + (long)(m0 + grp * 64 + trow) * p.ldc + c0 + (g4 >> 1) * 8;
-        u32x4 ax[2][4];
+        u32x4 ax[2][4];              // (all sixteen pieces requested at once - the K loop's fragment registers are free - measured slower: 16.9 vs 14.5 us of epilogue per tile, spills)
         auto load_aux = [&](int i, u32x4 (&dst)[4]) {
             const bf16_t* a_i = arow + (long)((i >> 1) * 128 + (i & 1) * 32) * p.ldc;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) dst[sidx] = *reinterpret_cast<const u32x4*>(a_i + (sidx & 1) * 16 + (sidx >> 1) * 128);
         };
         load_aux(0, ax[0]);
-        float sL = 0.f, sR = 0.f;
+        float cs[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) cs[e] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < 3) load_aux(i + 1, ax[(i + 1) & 1]);
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx)
-                *reinterpret_cast<u32x4*>(tl + trow * PA + ((g4 >> 1) + 2 * sidx) * 16) = ax[i & 1][sidx];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f32x16 l, r;
+            const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const char* src = tl + (8 * q + 4 * h2 + (a16 >> 2)) * PA + (((cl >> 4) * 16) + (a16 & 3) * 4) * 2;
-                const s16x4 tL = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
-                const s16x4 tR = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 64));
+                union { bf16_t h[4]; uint2 u; } pl, pr;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float al = half_bits_to_float(tL[e]), ar = half_bits_to_float(tR[e]);
-                    l[4 * q + e] = (acc[i][0][4 * q + e] * p.alpha + bL) * al;
-                    r[4 * q + e] = (acc[i][1][4 * q + e] * p.alpha + bR) * ar;
-                    sL += l[4 * q + e]; sR += r[4 * q + e];
+                    pl.h[e] = (bf16_t)(acc[i][0][4 * q + e] * p.alpha + bL);
+                    pr.h[e] = (bf16_t)(acc[i][1][4 * q + e] * p.alpha + bR);
                 }
+                *reinterpret_cast<uint2*>(tl + cl * TP + (8 * q + 4 * h2) * 2) = pl.u;
+                *reinterpret_cast<uint2*>(tl + (32 + cl) * TP + (8 * q + 4 * h2) * 2) = pr.u;
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+            bf16_t* drow = Cb + (long)(row0 + (g4 & 1) * 16 + a16) * p.ldc + c0 + (g4 >> 1) * 8;
+            const char* src0 = tl + ((g4 >> 1) * 8 + (a16 >> 2)) * TP + ((g4 & 1) * 16 + (a16 & 3) * 4) * 2;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const char* src = src0 + sidx * 16 * TP;
+                union { struct { s16x4 lo, hi; } s; bf16_t h[8]; } u;
+                u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src));
+                u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(src + 4 * TP));
+                union { u32x4 v; bf16_t h[8]; } a, o;
+                a.v = ax[i & 1][sidx];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = (float)u.h[e] * (float)a.h[e];
+                    cs[sidx * 8 + e] += pv;
+                    o.h[e] = (bf16_t)pv;
+                }
+                *reinterpret_cast<u32x4*>(drow + (sidx & 1) * 16 + (sidx >> 1) * 128) = o.v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (p.colsum) {
-            sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
-            if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
+            // lane L holds partials of columns c0 + (L >> 5) * 8 + (sidx & 1) * 16 + (sidx >> 1) * 128 + e, index sidx * 8 + e; the 32 lanes of a
+            // half-wave hold the same 32 columns: [lane][32] floats through the scratch, lane L then sums index L & 31 over its half
+            // (two passes of 16 indices: [lane][16] floats = 4 KiB, the scratch a wave owns in the persistent kernel is 4608 bytes)
+            float* fs = reinterpret_cast<float*>(tl);
+            const int idx = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(fs + lane * 16 + 4 * q) = make_float4(cs[16 * t + 4 * q], cs[16 * t + 4 * q + 1], cs[16 * t + 4 * q + 2], cs[16 * t + 4 * q + 3]);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float tot = 0.f;
+#pragma unroll
+                for (int l2 = 0; l2 < 16; ++l2) tot += fs[(half * 32 + part * 16 + l2) * 16 + idx];
+                tot += __shfl_xor(tot, 16, 64);
+                const int ci = 16 * t + idx, sidx = ci >> 3;
+                if (part == 0) atomicAdd(p.colsum + c0 + half * 8 + (sidx & 1) * 16 + (sidx >> 1) * 128 + (ci & 7), tot);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
     } else if (p.act == 0) {       // no activation (qkv forward, the plain dgrads): a small body, unrolled - no accumulator selects
 #pragma unroll

@@ -205,9 +205,9 @@ def test_gemm_pingpong_accumulator_layout_epilogues(ops, tb, M, N, K):
             "gelu3_d": x.grad, "gelu3_noaux": F.gelu(ref + bias), "times_aux": ref * aux.float(), "f32_res": ref + bias + res}
     for k, w in want.items():
         _close(results[3][k], w, 1e-5 if k.startswith("f32") else 1e-2, f"ping-pong {k}")
-    _close(results[3]["times_aux_colsum"], (ref * aux.float()).sum(0), 2e-4, "column sums in the accumulator layout")
+    _close(results[3]["times_aux_colsum"], (ref * aux.float()).sum(0), 4e-3, "column sums of the stored products")       # (the ping-pong epilogue rounds the matmul result to bf16 before the multiplication, as autocast does: 2^-9 per term)
     for k in results[3]:
-        tol = 1e-5 if k.startswith("f32") else (2e-4 if k.endswith("colsum") else 1e-2)
+        tol = 1e-5 if k.startswith("f32") else (4e-3 if k.endswith("colsum") else 1e-2)
         _close(results[3][k], results[1][k].float(), tol, f"ping-pong vs staged epilogue: {k}")
     d3, d1 = results[3]["f32_res_drop"] - res, results[1]["f32_res_drop"] - res
     assert float(((d3.abs() < 1e-6) != (d1.abs() < 1e-6)).float().mean()) < 1e-3          # the same dropout mask
@@ -261,7 +261,7 @@ def test_gemm_persistent_pingpong_kernel(ops, tb, M, N, K):
             "gelu3_d": x.grad, "gelu3_noaux": F.gelu(ref + bias), "times_aux": ref * aux.float(), "f32_res": ref + bias + res}
     for k, w in want.items():
         _close(results[10][k], w, 1e-5 if k.startswith("f32") else 1e-2, f"persistent {k}")
-    _close(results[10]["times_aux_colsum"], (ref * aux.float()).sum(0), 2e-4, "column sums")
+    _close(results[10]["times_aux_colsum"], (ref * aux.float()).sum(0), 4e-3, "column sums")
     for k in results[10]:
         if k.endswith("colsum"):
             continue                                                          # (atomic order differs)

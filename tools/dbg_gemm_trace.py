@@ -18,6 +18,10 @@ act = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 kw = {}
 if act == 3:
     kw = dict(act=3, bias=torch.zeros(N, device="cuda"), aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+elif act == 4:
+    kw = dict(act=4, aux=torch.randn(M, N, device="cuda").bfloat16(), colsum=torch.zeros(N, device="cuda"))
+elif act == 5:
+    kw = dict(bias=torch.zeros(N, device="cuda"), residual=torch.randn(M, N, device="cuda"), out_dtype=torch.float32)
 call("simseg_debug_gemm_stagger", stagger)
 a = torch.randn(M, K, device="cuda").bfloat16()
 b = (torch.randn(K, N, device="cuda") if kind == "nn" else torch.randn(N, K, device="cuda")).bfloat16()
