@@ -749,6 +749,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         kdesc = {"_P": "gemm_pp_kernel (256x256 tile, two wave groups in ping-pong, direct-to-LDS half-tile ring)",
+                 "_Q": "gemm_pp2_kernel (persistent 256x256 ping-pong: one workgroup per CU walks its XCD's tiles, operand copies and the epilogue's stores run across tile boundaries)",
                  "_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)"}.get(dom[-2:], "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)")
         out = {
             "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",

@@ -1556,7 +1556,7 @@ bool pp2_ok(const GemmParams& p, int splitk) {
 }
 
 template <typename TO, bool TA, bool TB, int SCHED = 0>
-int launch_pp2(const GemmParams& p, hipStream_t stream) {
+int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
     static int blocks = 0;
@@ -1572,7 +1572,10 @@ int launch_pp2(const GemmParams& p, hipStream_t stream) {
     }
     GemmParams q = p;
     q.ksplit = p.K / 64; q.nsplit = 1;
-    hipLaunchKernelGGL(kern, dim3(blocks, 1, 1), dim3(512), SMEM, stream, q);
+    // reserve > 0 (variant 18): that many CUs are left to the kernels of the other stream - a persistent launch never hands a CU back, so
+    // without a reserve the other tower's kernels wait for whole GEMM launches (the -6.7 % of round 3's first half)
+    const int nb = reserve > 0 ? ((blocks - reserve) & ~7) : blocks;
+    hipLaunchKernelGGL(kern, dim3(nb < 8 ? 8 : nb, 1, 1), dim3(512), SMEM, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm(persistent ping-pong)");
     return 0;
 }
@@ -1735,7 +1738,7 @@ template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
     const bool big_ok = aligned && p.K % 64 == 0 && p.M >= 256 && p.N >= 128;
     const bool four_phase = g_gemm_variant == 15;       // 15 = the automatic choice, ping-pong kernel on its four-phase schedule (A/B runs)
-    int v = (four_phase || g_gemm_variant == 16) ? 0 : g_gemm_variant;
+    int v = (four_phase || g_gemm_variant == 16 || g_gemm_variant == 18) ? 0 : g_gemm_variant;
     const int nk64 = p.K / 64;
     const int kper = (nk64 + (splitk > 1 ? splitk : 1) - 1) / (splitk > 1 ? splitk : 1);   // 64-deep slabs per block
     // measured (profiles/r1_gemm_variants.txt, after the epilogue was rolled to fit the instruction cache): the 256x256
@@ -1784,12 +1787,24 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     if (v == 3 || (v >= 10 && v <= 13)) {
         // more than one round of full tiles with an accumulator-layout epilogue: the persistent kernel (10 forces it wherever it
         // applies, 3 forces the per-tile kernel - A/B runs)
-        // Opt-in only (variant 10; 11-13 its schedule experiments).  Measured (profiles/r3_gemm_persistent_ab.txt): +6 % over the
-        // per-tile kernel on the training shapes in isolation, +1-3 % inside a single-stream training step - and -6.7 % on the default
-        // two-stream step (100.1 vs 93.8 ms): a persistent launch owns every CU for its whole duration (512 threads x 256 VGPRs, 144 KiB
-        // of LDS per CU: nothing co-resides), so the other tower's kernels - GEMM tiles, LayerNorm, attention - no longer slip into
-        // the tails and memory-bound phases of this tower's; the per-tile kernel hands its CUs back after every tile.
+        // (variant 10 forces it wherever it applies, 11-13 are its schedule experiments; profiles/r3_gemm_persistent_ab.txt: +6 % over the
+        // per-tile kernel on the training shapes in isolation)
         if constexpr (!TA) {
+            // The persistent kernel is the default for problems of >= 600 full tiles (SIMSEG_GEMM_PP2_MIN_TILES; variant 3 forces the per-tile
+            // kernel).  Measured in the default two-stream training step, same box, two rounds each: 90.9-91.4 ms per-tile -> 88.1-88.4 ms
+            // (thresholds 257..1100 within 0.3 ms of each other, 2000: 89.5); single stream 94.9 -> 93.8 ms.  The first half of round 3 had
+            // found the opposite (100.1 vs 93.8 ms) - with variant 10, which ALSO takes the split-K weight gradients off the ping-pong kernel
+            // (the `v >= 10 && !(big_ok && !TA)` rule below sends them to the 128x128 kernel): that, not the persistence, was the loss.
+            // SIMSEG_GEMM_PP2_RESERVE leaves CUs to the other stream's kernels (0, 8, 32 measured within 0.4 ms; 40+ slower): default 0.
+            static int reserve = -1, min_tiles = -1;
+            if (reserve < 0) {
+                const char* e = getenv("SIMSEG_GEMM_PP2_RESERVE"); reserve = e ? atoi(e) : 0;
+                e = getenv("SIMSEG_GEMM_PP2_MIN_TILES"); min_tiles = e ? atoi(e) : 600;
+            }
+            if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && pp2_ok<TO>(p, splitk)) {
+                g_gemm_last_variant = 10;
+                return launch_pp2<TO, TA, TB, 0>(p, s, reserve);
+            }
             if (g_gemm_variant >= 10 && g_gemm_variant <= 13 && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
                 switch (g_gemm_variant) {           // 11..13: schedule experiments (see SCHED)

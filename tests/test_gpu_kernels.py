@@ -266,7 +266,7 @@ def test_gemm_persistent_pingpong_kernel(ops, tb, M, N, K):
         if k.endswith("colsum"):
             continue                                                          # (atomic order differs)
         assert torch.equal(results[10][k], results[3][k]), f"persistent vs per-tile kernel: {k} differs"
-    # the persistent kernel is opt-in (it owns every CU for its whole launch: slower under the two-stream tower schedule)
+    # the automatic choice takes the persistent kernel from 600 full tiles on (test_gemm_auto_takes_the_persistent_kernel_for_many_tiles); these are smaller
     ops.gemm(a, b, trans_b=tb)
     assert raw("simseg_gemm_last_variant") == (3 if K >= 768 else 1)       # (short contractions stay on the 128x128 kernel)
     # repeated launches are independent (no state carried in the ring / scratch between launches)
@@ -902,3 +902,27 @@ def test_patch_text_sim_fused(ops, dtype, M, C, K):
     _close(got, ref, 1e-5 if dtype == torch.float32 else 1e-5, f"fused sim map {M}x{C}x{K}")
     plain = ops.patch_text_sim(x, t, normalize=False)
     _close(plain, x.float() @ t.float().T, 1e-5, "plain contraction")
+
+
+def test_gemm_auto_takes_the_persistent_kernel_for_many_tiles(ops):
+    """From 600 full 256x256 tiles on (the image tower's training GEMMs) the automatic dispatch launches the persistent ping-pong kernel;
+    same bits as the per-tile kernel; problems with a ragged edge or fewer tiles stay on the per-tile kernel."""
+    from simseg_amd.lib import raw
+    M, N, K = 256 * 210, 768, 768
+    a = _rand(M, K, seed=1, dtype=torch.bfloat16)
+    b = _rand(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    y = ops.gemm(a, b, bias=bias)
+    assert raw("simseg_gemm_last_variant") == 10
+    y32 = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert raw("simseg_gemm_last_variant") == 10
+    ops.set_gemm_variant(3)
+    try:
+        assert torch.equal(ops.gemm(a, b, bias=bias), y) and raw("simseg_gemm_last_variant") == 3
+        assert torch.equal(ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32), y32)
+    finally:
+        ops.set_gemm_variant(0)
+    ops.gemm(a[:M - 7], b, bias=bias)
+    assert raw("simseg_gemm_last_variant") == 3                       # a ragged last row tile
+    ops.gemm(a[:256 * 150], b, bias=bias)
+    assert raw("simseg_gemm_last_variant") == 3                       # 450 tiles
