@@ -185,7 +185,9 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     resize/argmax and IoU histograms on the device (tools/seg_evaluation.py:99-170 without the CPU CRF stage).  Independent
     windows: sharded over ranks, no collective on the data path (one all-reduce of the [3,C] histograms at the end).
     Batch = 21 source images of 3 windows: 63 x 1025 tokens = 252.2 row panels of 256, i.e. the GEMM tile grids (759 / 2277 /
-    3036 tiles) fill their last round of 256 CUs to 97-99 %; 64 windows would be 257 panels = 3.01 rounds for N = 768."""
+    3036 tiles) fill their last round of 256 CUs to 97-99 %; 64 windows would be 257 panels = 3.01 rounds for N = 768.  The bf16 legs run 256
+    windows per batch instead (round 3): every GEMM row count is then a multiple of 256 - full tiles only - and the persistent ping-pong
+    kernel takes them (+5 % ViT-B, +15 % ViT-S; the exact-mode legs measured no better with it: tools/seg_windows_ab.py)."""
     from simseg_amd.heads import patch_text_similarity
     from simseg_amd import ops
     from simseg.models import PIPELINE
@@ -689,13 +691,13 @@ def main():
     torch.cuda.empty_cache()
     seg = None
     if not args.no_seg:
-        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16"),
+        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16", windows=256),
                # the same stage with the reference's DenseCRF in (device mean field on permutohedral lattices, tools/seg_evaluation.py:153)
-               "fp32_crf": seg_eval_bench(dev, world, "fp32", crf=True, steps=1), "bf16_crf": seg_eval_bench(dev, world, "bf16", crf=True, steps=1),
+               "fp32_crf": seg_eval_bench(dev, world, "fp32", crf=True, steps=1), "bf16_crf": seg_eval_bench(dev, world, "bf16", crf=True, steps=1, windows=256),
                "vit_s_288_fp32_crf": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
                # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
                "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
-               "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
+               "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
         if rank == 0:         # single-image latency (the reference tool's batch size), eager launches vs one hipGraph replay
             seg["latency_batch1"] = [seg_latency_bench(dev, "fp32", 288, 21, "vit_small_patch16_224_in21k", 384),
                                      seg_latency_bench(dev, "fp32", 512, 171, "vit_base_patch16_224_in21k", 768),
