@@ -856,6 +856,9 @@ struct PPFrag {
 // bias / GELU run on the accumulators in MFMA layout (a lane owns ONE column: the bias is a scalar per lane), pairs of rows are packed to
 // bf16, staged TRANSPOSED ([column][row], 8-byte writes) in the wave's 4608-byte scratch `tl` and read back through ds_read_b64_tr_b16, which
 // hands every lane 4 consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per 32x64 block.
+// A4 = false: an instantiation without the times-saved-derivative branch (its 32 column-sum partials and operand sets set the kernel's
+// register high-water mark: with them compiled in, state that lives across the K loop is parked in scratch around EVERY tile)
+template <bool A4 = true>
 __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x16 (&acc)[4][2], char* tl, int m0, int c0, int c1, int grp, int lane) {
     constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
     const int cl = lane & 31, h2 = lane >> 5, g4 = lane >> 4, a16 = lane & 15;
@@ -889,7 +892,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    if (p.act == 4) {
+    if (A4 && p.act == 4) {
         // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
         // output, and `emit` hands every lane its results as 16-byte row pieces - the very pieces (same row, same eight columns) a 16-byte
         // load of the saved tensor returns.  So the product is formed THERE, on the way out: eight bf16 x bf16 -> fp32 products per piece,
@@ -1060,7 +1063,7 @@ __device__ __forceinline__ void pp_epilogue_f32_direct(const GemmParams& p, cons
 // phase Y reads A half 1 (8 reads), stages B half 0 / A half 0 / B half 1 of the K-tile after next (6 copies: those slots were last read
 // in phase X) and multiplies A half 1 by both B halves.  Every half-tile is requested two phases (one K-tile) before it is read;
 // vmcnt(8) in every phase.  Half as many barrier pairs per MFMA.
-template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1, int BIG = 0>
+template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1, int BIG = 0, bool A4 = true>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1250,10 +1253,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
         // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
         const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && p.row_group == 0 && !p.drop_thresh && !p.dbg_skip_epilogue &&
-                            (p.act == 0 || p.act == 1 || p.act == 3 || (p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
+                            (p.act == 0 || p.act == 1 || p.act == 3 || (A4 && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
-            pp_epilogue_bf16(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
+            pp_epilogue_bf16<A4>(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
             if (pf_ok) wait_vm<16>();                                // >= 16 stores were issued after the tail's copies: those have landed
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
@@ -1303,11 +1306,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1, int BIG = 0>
+template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1, int BIG = 0, bool A4 = true>
 int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
-    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO, BIG>;
+    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO, BIG, A4>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
@@ -1370,7 +1373,7 @@ __device__ __forceinline__ PP2Item pp2_item(const GemmParams& p, int t, int tile
 // SCHED (where a phase's two global->LDS copies are issued; the load segment of a phase - fragment reads + copies + waits - measured
 // longer than the 8-MFMA segment it is supposed to hide under): 0 = both in the load segment (the per-tile kernel's order), 1 = both
 // inside the wave's own MFMA cluster, 2 = one and one, 3 = both in the load segment but ahead of the fragment reads.
-template <typename TO, bool TA, bool TB, int SCHED = 0>
+template <typename TO, bool TA, bool TB, int SCHED = 0, bool A4 = true>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1513,7 +1516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p) {
         if constexpr (sizeof(TO) == 2) {
             const unsigned lp = cpar ^ 1u;
             char* tl = lds + (wave < 7 ? lp * (2 * PP_HALF) + wave * 4608 : PP_BREG + (lp * 2 + 1) * PP_HALF);
-            pp_epilogue_bf16(p, acc, tl, cur.m0, c0, c1, grp, lane);
+            pp_epilogue_bf16<A4>(p, acc, tl, cur.m0, c0, c1, grp, lane);
         } else {
             pp_epilogue_f32_direct(p, acc, cur.m0, c0, c1, grp, lane);
         }
@@ -1555,12 +1558,12 @@ bool pp2_ok(const GemmParams& p, int splitk) {
     return !p.aux && p.act == 0 && !p.colsum && !p.accumulate;
 }
 
-template <typename TO, bool TA, bool TB, int SCHED = 0>
+template <typename TO, bool TA, bool TB, int SCHED = 0, bool A4 = true>
 int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
     static int blocks = 0;
-    auto kern = gemm_pp2_kernel<TO, TA, TB, SCHED>;
+    auto kern = gemm_pp2_kernel<TO, TA, TB, SCHED, A4>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
@@ -1801,9 +1804,14 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
                 const char* e = getenv("SIMSEG_GEMM_PP2_RESERVE"); reserve = e ? atoi(e) : 0;
                 e = getenv("SIMSEG_GEMM_PP2_MIN_TILES"); min_tiles = e ? atoi(e) : 600;
             }
-            if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && pp2_ok<TO>(p, splitk)) {
+            // (the times-saved-derivative epilogue stays on the per-tile kernel unless SIMSEG_GEMM_PP2_ACT4=1: beside the persistent kernel's tile-walking
+            //  state its 32 column-sum partials spill - 0.709 vs 0.709 ms on the fc2 dgrad, 2-6 % slower on the other shapes, tools/gemm_ab.py --act 4)
+            static int act4 = -1;
+            if (act4 < 0) { const char* e = getenv("SIMSEG_GEMM_PP2_ACT4"); act4 = e ? atoi(e) : 0; }
+            if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && (p.act != 4 || act4) && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
-                return launch_pp2<TO, TA, TB, 0>(p, s, reserve);
+                if (p.act == 4) return launch_pp2<TO, TA, TB, 0, true>(p, s, reserve);
+                return launch_pp2<TO, TA, TB, 0, false>(p, s, reserve);
             }
             if (g_gemm_variant >= 10 && g_gemm_variant <= 13 && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
@@ -1817,7 +1825,10 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         }
         g_gemm_last_variant = 3;
         // 16-MFMA phases (round 3) unless variant 15 asks for the four-phase schedule (A/B runs)
-        if (!four_phase && p.K >= 128) return launch_pp<TO, TA, TB, 4, 1, 1>(p, splitk, s);
+        if (!four_phase && p.K >= 128) {
+            if (sizeof(TO) == 2 && p.act != 4) return launch_pp<TO, TA, TB, 4, 1, 1, false>(p, splitk, s);
+            return launch_pp<TO, TA, TB, 4, 1, 1>(p, splitk, s);
+        }
         return launch_pp<TO, TA, TB>(p, splitk, s);
     }
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);
