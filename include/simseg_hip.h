@@ -45,6 +45,12 @@ int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int
                 const float* rowscale, const float* residual, int64_t ldr, int act, const void* aux, void* aux_out,
                 int row_group, int res_mod, int accumulate, int splitk, uint64_t drop_seed, float drop_p, float* colsum,
                 void* stream);
+/* act codes 5 / 6 of simseg_gemm = 3 / 4 (GELU with its derivative saved / times the saved derivative + column sums) with the saved tensor in
+ * a tile-blocked layout private to the two calls: the fc1 forward and the dgrad through fc2 are the same M x N x K problem on the same
+ * 256x256 tiling, so the derivative is stored as it lies in the accumulator registers and read back the same way (no transposition on
+ * either side).  Allowed when this returns 1 for the problem (full tiles on the ping-pong kernels); aux / aux_out stay [M, N] 16-bit
+ * allocations whose content is opaque. */
+int simseg_gemm_aux_blocked_ok(int64_t M, int64_t N, int64_t K);
 
 /* K14, the dense zero-shot segmentation map: out[m,c] = < x[m,:] / max(||x[m,:]||, eps), text[c,:] > for every patch row m
  * and every class c (C <= 256) in one pass over x, the row L2-normalisation (F.normalize, tools/seg_evaluation.py:112) fused

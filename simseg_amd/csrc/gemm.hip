@@ -60,6 +60,7 @@ struct GemmParams {
     unsigned long long drop_seed; unsigned int drop_thresh; float drop_scale;
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the producing layer)
     int pf_next;             // ping-pong kernel: the tail's copies fetch the next tile of this XCD (see gemm_pp_kernel)
+    int aux_blocked;         // act 3 / 4 on the ping-pong kernels: aux_out / aux is the tile-blocked accumulator image (simseg_gemm act codes 5 / 6)
 };
 
 template <typename T> struct TT;
@@ -892,7 +893,65 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    if (A4 && p.act == 4) {
+    // Tile-blocked accumulator image of the saved GELU' (act codes 5 / 6 of simseg_gemm): the fc1 forward and the dgrad through fc2 are the
+    // same M x N x K problem on the same tiling, and the derivative is computed - and consumed - with a lane owning a column and its
+    // registers the rows.  Stored as it lies in the registers ([tile][wave slot][32-row block][column half][lane][16 rows], 32 bytes per
+    // lane, 1 KiB per wave-instruction pair, fully coalesced) it needs no transposition on either side: the forward drops the second
+    // trip through the staging scratch, the backward loads 32 bytes per lane straight into the accumulator layout, multiplies in fp32
+    // (one rounding, exact column sums from two registers) and stores through the plain path.  Opaque to everything else: the tensor
+    // is only ever handed from the one call to the other.
+    const long blk0 = ((((long)(m0 >> 8) * (p.N >> 8) + (c0 >> 8)) * 8 + grp * 4 + ((c0 & 255) >> 5)) * 8) * 1024 + lane * 16;      // + (i * 2 + j) * 1024
+    if (p.act == 4 && p.aux_blocked) {
+        const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux) + blk0;
+        u32x4 ax[2][4];                                      // [buffer][j * 2 + half]: 16 rows of the left / right column
+        auto load_blk = [&](int i, u32x4 (&dst)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const u32x4*>(Ab + (i * 2 + (q >> 1)) * 1024 + (q & 1) * 8);
+        };
+        load_blk(0, ax[0]);
+        float sL = 0.f, sR = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) load_blk(i + 1, ax[(i + 1) & 1]);
+            f32x16 l, r;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                union { u32x4 v; bf16_t h[8]; } gl, gr;
+                gl.v = ax[i & 1][q]; gr.v = ax[i & 1][2 + q];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    l[8 * q + e] = (acc[i][0][8 * q + e] * p.alpha + bL) * (float)gl.h[e];
+                    r[8 * q + e] = (acc[i][1][8 * q + e] * p.alpha + bR) * (float)gr.h[e];
+                    sL += l[8 * q + e]; sR += r[8 * q + e];
+                }
+            }
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+        if (p.colsum) {
+            sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
+            if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
+        }
+    } else if (p.act == 3 && Xb && p.aux_blocked) {
+        bf16_t* Bb = Xb + blk0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x16 l, r;
+            union { u32x4 v[2]; bf16_t h[16]; } dl, dr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float d0, d1;
+                l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
+                r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
+                dl.h[e] = (bf16_t)d0; dr.h[e] = (bf16_t)d1;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<u32x4*>(Bb + (i * 2) * 1024 + q * 8) = dl.v[q];
+                *reinterpret_cast<u32x4*>(Bb + (i * 2 + 1) * 1024 + q * 8) = dr.v[q];
+            }
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+    } else if (A4 && p.act == 4) {
         // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
         // output, and `emit` hands every lane its results as 16-byte row pieces - the very pieces (same row, same eight columns) a 16-byte
         // load of the saved tensor returns.  So the product is formed THERE, on the way out: eight bf16 x bf16 -> fp32 products per piece,
@@ -1253,7 +1312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
         // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
         const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && p.row_group == 0 && !p.drop_thresh && !p.dbg_skip_epilogue &&
-                            (p.act == 0 || p.act == 1 || p.act == 3 || (A4 && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
+                            (p.act == 0 || p.act == 1 || p.act == 3 || ((A4 || p.aux_blocked) && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
             pp_epilogue_bf16<A4>(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
@@ -1787,6 +1846,8 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     }
     if (!big_ok) v = 1;
     g_gemm_last_variant = v;
+    if (p.aux_blocked && !(v == 3 || (v >= 10 && v <= 13)))
+        return simseg_set_error("simseg_gemm: act 5 / 6 (tile-blocked saved derivative) needs the 256x256 ping-pong kernel; this call dispatches to variant %d", v);
     if (v == 3 || (v >= 10 && v <= 13)) {
         // more than one round of full tiles with an accumulator-layout epilogue: the persistent kernel (10 forces it wherever it
         // applies, 3 forces the per-tile kernel - A/B runs)
@@ -1808,9 +1869,9 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
             //  state its 32 column-sum partials spill - 0.709 vs 0.709 ms on the fc2 dgrad, 2-6 % slower on the other shapes, tools/gemm_ab.py --act 4)
             static int act4 = -1;
             if (act4 < 0) { const char* e = getenv("SIMSEG_GEMM_PP2_ACT4"); act4 = e ? atoi(e) : 0; }
-            if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && (p.act != 4 || act4) && pp2_ok<TO>(p, splitk)) {
+            if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && (p.act != 4 || p.aux_blocked || act4) && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
-                if (p.act == 4) return launch_pp2<TO, TA, TB, 0, true>(p, s, reserve);
+                if (p.act == 4 && !p.aux_blocked) return launch_pp2<TO, TA, TB, 0, true>(p, s, reserve);
                 return launch_pp2<TO, TA, TB, 0, false>(p, s, reserve);
             }
             if (g_gemm_variant >= 10 && g_gemm_variant <= 13 && pp2_ok<TO>(p, splitk)) {
@@ -1826,7 +1887,7 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         g_gemm_last_variant = 3;
         // 16-MFMA phases (round 3) unless variant 15 asks for the four-phase schedule (A/B runs)
         if (!four_phase && p.K >= 128) {
-            if (sizeof(TO) == 2 && p.act != 4) return launch_pp<TO, TA, TB, 4, 1, 1, false>(p, splitk, s);
+            if (sizeof(TO) == 2 && (p.act != 4 || p.aux_blocked)) return launch_pp<TO, TA, TB, 4, 1, 1, false>(p, splitk, s);
             return launch_pp<TO, TA, TB, 4, 1, 1>(p, splitk, s);
         }
         return launch_pp<TO, TA, TB>(p, splitk, s);
@@ -1870,6 +1931,13 @@ extern "C" int simseg_patch_text_sim(const void* x, const void* text, float* out
     return dispatch_simmap<bf16_t>(x, text, out, (int)M, (int)C, (int)K, eps, normalize, (hipStream_t)stream);
 }
 
+// 1 when a 16-bit M x N x K problem (k-contiguous A) runs on the 256x256 ping-pong kernels with full tiles only - the condition under which
+// the fc1 forward may save GELU' as the tile-blocked accumulator image (act 5) for the dgrad through fc2 (act 6) to read back
+extern "C" int simseg_gemm_aux_blocked_ok(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 64 || K < 768) return 0;
+    return (M / 256) * (N / 256) >= 96;
+}
+
 // dtype codes: 0 = fp32, 1 = bf16
 extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                            int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, int transA, int transB, float alpha,
@@ -1894,8 +1962,16 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f && !colsum),
              "simseg_gemm: split-K needs a plain fp32 accumulate epilogue");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "simseg_gemm: dropout p out of range");
+    SS_CHECK(act >= 0 && act <= 6, "simseg_gemm: act must be 0..6");
+    const int blocked = act >= 5;
+    if (blocked) {       // 5 / 6 = 3 / 4 with the saved derivative as the tile-blocked accumulator image (include/simseg_hip.h)
+        SS_CHECK(simseg_gemm_aux_blocked_ok(M, N, K) && in_dtype == 1 && out_dtype == 1 && !transA && !rowscale && !residual && row_group == 0 &&
+                 drop_p == 0.f && splitk <= 1 && ldc == N && (act == 5 ? aux_out != nullptr : aux != nullptr) &&
+                 ((uintptr_t)(act == 5 ? aux_out : aux) % 16) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
+                 "simseg_gemm: act %d needs a full-tile 16-bit problem on the ping-pong kernel (simseg_gemm_aux_blocked_ok) with a plain epilogue", act);
+        act -= 2;
+    }
     SS_CHECK((act != 2 && act != 4) || aux, "simseg_gemm: act=2/4 needs aux");
-    SS_CHECK(act >= 0 && act <= 4, "simseg_gemm: act must be 0..4");
     SS_CHECK(!res_mod || row_group > 0, "simseg_gemm: res_mod needs row_group");
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -1907,6 +1983,7 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     p.colsum = colsum;
     p.drop_thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    p.aux_blocked = blocked;
     p.pf_next = g_gemm_variant != 16;                                // 16 = automatic choice without the next-tile fetch (A/B runs)
     hipStream_t s = (hipStream_t)stream;
     g_gemm_last_variant = 1;

@@ -89,6 +89,19 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
     return out
 
 
+_BLK_OK = {}
+
+
+def gemm_aux_blocked_ok(M, N, K):
+    """May the fc1 forward save GELU' as the tile-blocked accumulator image (act 5) for the dgrad through fc2 (act 6)?  (include/simseg_hip.h:
+    full 256x256 tiles on the ping-pong kernels.)  SIMSEG_AMD_BLOCKED_AUX=0 keeps the row-major tensor (A/B runs)."""
+    key = (int(M), int(N), int(K))
+    r = _BLK_OK.get(key)
+    if r is None:
+        r = _BLK_OK[key] = os.environ.get("SIMSEG_AMD_BLOCKED_AUX", "1") != "0" and bool(raw("simseg_gemm_aux_blocked_ok", *key))
+    return r
+
+
 def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, want_bf16_copy=False, save_stats=False):
     require_gpu(x)
     D = x.shape[-1]

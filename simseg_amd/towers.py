@@ -425,9 +425,11 @@ class ViTBlockFn(_GradAwareFn):
         x1 = ops.gemm(att.view(-1, D), pw_, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
         ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=save)
         pre = torch.empty(B * T, 4 * D, device=x.device, dtype=adt) if save else None
-        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=3 if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
+        # (16-bit modes, full tiles: GELU' is saved as the tile-blocked accumulator image the dgrad through fc2 reads back - act 5 / 6)
+        blk = save and adt != F32 and ops.gemm_aux_blocked_ok(B * T, 4 * D, D)
+        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=(5 if blk else 3) if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
         y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
-        ctx.adt, ctx.heads, ctx.dims = adt, heads, (B, T, D)
+        ctx.adt, ctx.heads, ctx.dims, ctx.blk = adt, heads, (B, T, D), blk
         if save:
             ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_,
                                   n1w.detach(), n2w.detach())
@@ -451,7 +453,7 @@ class ViTBlockFn(_GradAwareFn):
         (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros(
             dy.device, (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
-        dpre = _dgrad(dy16, f2w_, act=4, aux=pre, colsum=df1b)
+        dpre = _dgrad(dy16, f2w_, act=6 if ctx.blk else 4, aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
         dln2 = _dgrad(dpre, f1w_)
         df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
@@ -633,12 +635,13 @@ class BertLayerFn(_GradAwareFn):
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt if adt != F32 else False), save_stats=save)
         aa = a32 if adt == F32 else a16
         pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
-        act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=3 if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
+        blk = save and adt != F32 and ops.gemm_aux_blocked_ok(aa.shape[0], iw.shape[0], D)
+        act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=(5 if blk else 3) if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = _fwd_gemm(act, o2w, adt, save, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt if (adt != F32 and packed) else False), save_stats=save)
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
-        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv
+        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv, ctx.blk = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv, blk
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
                                   law.detach(), low.detach(), attd if (packed and not rows) else None, idx, inv, cu if rows else None)
@@ -659,7 +662,7 @@ class BertLayerFn(_GradAwareFn):
             dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
         ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt != F32 else dy, dy32=dy if adt != F32 else None,
                              dxsum=do2b, drop=(p, seed + 2))
-        dpre = _dgrad(d2, o2w_, act=4, aux=pre, colsum=dib)
+        dpre = _dgrad(d2, o2w_, act=6 if ctx.blk else 4, aux=pre, colsum=dib)
         do2w = _wgrad(d2, act, do2w_z) if need[18] else None
         # gradient reaching LN_a's output: through the intermediate dense (da) + the residual branch (ds2_32); bf16 mode adds them
         # inside the LayerNorm kernel, exact mode in the GEMM's residual epilogue

@@ -926,3 +926,41 @@ def test_gemm_auto_takes_the_persistent_kernel_for_many_tiles(ops):
     assert raw("simseg_gemm_last_variant") == 3                       # a ragged last row tile
     ops.gemm(a[:256 * 150], b, bias=bias)
     assert raw("simseg_gemm_last_variant") == 3                       # 450 tiles
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(256 * 40, 768, 768, 0), (256 * 210, 768, 768, 0), (256 * 210, 768, 768, 3), (256 * 33, 3072, 768, 0)])
+def test_gemm_saved_derivative_as_tile_blocked_image(ops, M, N, K, variant):
+    """act 5 / 6: the fc1 forward stores GELU' as it lies in the accumulator registers of its tile, the dgrad through fc2 reads it back the
+    same way - same results as the row-major pair (act 3 / 4), on the per-tile and the persistent kernel, and across the two (a tensor
+    written by one kernel is read by the other: the layout is a function of the tile, not of the kernel)."""
+    from simseg_amd.lib import raw
+    assert raw("simseg_gemm_aux_blocked_ok", M, N, K) == 1 and raw("simseg_gemm_aux_blocked_ok", M + 8, N, K) == 0
+    a = _rand(M, K, seed=1, dtype=torch.bfloat16)
+    b = _rand(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16)
+    g = _rand(M, K, seed=6, dtype=torch.bfloat16)
+    w2 = _rand(K, N, seed=7, scale=K ** -0.5, dtype=torch.bfloat16)          # [out = K, in = N]: the dgrad through it is g @ w2 -> [M, N]
+    bias = _rand(N, seed=3)
+    ops.set_gemm_variant(variant)
+    try:
+        d_row = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        y_row = ops.gemm(a, b, bias=bias, act=3, aux_out=d_row)
+        d_blk = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        y_blk = ops.gemm(a, b, bias=bias, act=5, aux_out=d_blk)
+        assert raw("simseg_gemm_last_variant") in (3, 10)
+        assert torch.equal(y_row, y_blk)
+        assert torch.equal(d_row.flatten().float().sort().values, d_blk.flatten().float().sort().values)       # the same values, tile-blocked order
+        assert not torch.equal(d_row, d_blk)
+        cs_row, cs_blk = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        dx_row = ops.gemm(g, w2, trans_b=True, act=4, aux=d_row, colsum=cs_row)
+        dx_blk = ops.gemm(g, w2, trans_b=True, act=6, aux=d_blk, colsum=cs_blk)
+        want = (g.float() @ w2.float()) * d_row.float()
+        _close(dx_blk, want, 1e-2, "times the tile-blocked derivative")
+        _close(dx_row, want, 1e-2, "times the row-major derivative")
+        _close(cs_blk, want.sum(0), 2e-4, "column sums (fp32 products)")
+        # the other kernel reads what this one wrote
+        ops.set_gemm_variant(3 if variant == 0 else 0)
+        _close(ops.gemm(g, w2, trans_b=True, act=6, aux=d_blk), dx_blk.float(), 1e-6, "blocked image across kernels")
+    finally:
+        ops.set_gemm_variant(0)
+    with pytest.raises(RuntimeError, match="act 5"):
+        ops.gemm(a[:M - 8], b, bias=bias, act=5, aux_out=d_blk[:M - 8])
