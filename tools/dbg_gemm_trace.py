@@ -20,6 +20,10 @@ if act == 3:
     kw = dict(act=3, bias=torch.zeros(N, device="cuda"), aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
 elif act == 4:
     kw = dict(act=4, aux=torch.randn(M, N, device="cuda").bfloat16(), colsum=torch.zeros(N, device="cuda"))
+elif act == 13:      # simseg_gemm act 5: GELU stored, GELU' saved as the tile-blocked accumulator image
+    kw = dict(act=5, bias=torch.zeros(N, device="cuda"), aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+elif act == 14:      # simseg_gemm act 6: times the tile-blocked saved derivative + column sums
+    kw = dict(act=6, aux=torch.randn(M, N, device="cuda").bfloat16(), colsum=torch.zeros(N, device="cuda"))
 elif act == 5:
     kw = dict(bias=torch.zeros(N, device="cuda"), residual=torch.randn(M, N, device="cuda"), out_dtype=torch.float32)
 call("simseg_debug_gemm_stagger", stagger)
