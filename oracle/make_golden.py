@@ -327,7 +327,7 @@ def gold_clip_glue():
           img_tok=_np(img_tok), txt_feat=_np(txt_feat), txt_emb=_np(txt_emb), **sd)
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, group_size=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -337,10 +337,23 @@ def _dist_worker(rank, world, port, q):
     import simseg.models.criteria.losses.mml_loss as rloss
     from simseg.utils import ENV
     ENV.rank, ENV.local_rank, ENV.size = rank, rank, world
-    # utils/dist.py:195 moves pickled bytes to a HIP device; on CPU the world group is the only group we need
-    rloss.generate_local_groups = lambda group_size: (dist.group.WORLD, rank)
-    rdist.generate_local_groups = rloss.generate_local_groups
-    model = _build_reference_clip([], rank)      # global_reduce=True, gather_backward=True (YAML)
+    if group_size is None:
+        # utils/dist.py:195 moves pickled bytes to a HIP device; on CPU the world group is the only group we need
+        rloss.generate_local_groups = lambda group_size: (dist.group.WORLD, rank)
+        rdist.generate_local_groups = rloss.generate_local_groups
+        extra = []
+    else:
+        # the 4-rank fixtures run the reference's REAL generate_local_groups (utils/dist.py:371-427: host-by-host packing, new_group on
+        # every rank) and its own all_gather_object (:168-223).  The only thing that cannot run here is the device move at :195 / :198 /
+        # :208 (`.to(my_local_rank)`, a HIP device index): ENV.local_rank is the string "cpu" while the loss is built, so those moves are
+        # no-ops and not one line of the reference is replaced.
+        ENV._local_rank = "cpu"                     # (the property's setter insists on an int)
+        extra = [f"loss.group_size={group_size}"]
+    model = _build_reference_clip(extra, rank)      # global_reduce=True, gather_backward=True (YAML)
+    ENV.local_rank = rank
+    if group_size is not None:
+        want_rank = rank % group_size                # one host: consecutive ranks share a group
+        assert model.loss.rank == want_rank and dist.get_world_size(model.loss.group) == group_size, (model.loss.rank, group_size)
     model.eval()
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     batch = _tiny_batch(3, 200 + rank)
@@ -351,8 +364,12 @@ def _dist_worker(rank, world, port, q):
              "image_encoder.model.model.blocks.0.attn.qkv.weight", "image_encoder.model.model.pos_embed",
              "text_encoder.model.model.encoder.layer.1.output.dense.weight",
              "text_encoder.model.model.embeddings.word_embeddings.weight"]
+    if group_size is not None:
+        names = names[:-1]                            # (the 4-rank fixtures leave out the [vocab, D] gradient: 0.5 MB per rank)
     params = dict(model.named_parameters())
     grads = {n: _np(params[n].grad) for n in names}
+    if group_size is not None:                        # (4-rank fixtures: the first 16 rows of the large matrices - 4 ranks x 2 files)
+        grads = {n: (v[:16] if v.ndim == 2 and v.shape[0] > 64 else v) for n, v in grads.items()}
     # pure-loss fixture: NCE on given embeddings with ignore_mask and label smoothing off/on
     g = torch.Generator().manual_seed(300 + rank)
     f1 = torch.nn.functional.normalize(torch.randn(8, 512, generator=g), dim=-1).requires_grad_(True)
@@ -377,30 +394,36 @@ def _dist_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def gold_dist(world):
+def gold_dist(world, group_size=None):
+    """clip_train_ws{world}.npz (loss over the whole world) / clip_train_ws{world}g{group_size}.npz (cfg.loss.group_size sub-groups,
+    mml_loss.py:24-27): every rank's batch, loss, accuracies, selected parameter gradients and a pure-NCE case, from a gloo run of the
+    reference."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29611 + world
-    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29611 + world + (10 * group_size if group_size else 0)
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, q, group_size)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(world))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join()
     flat = {}
     for r in range(world):
         for k, v in res[r].items():
             flat[k if k.startswith("sd.") else f"r{r}.{k}"] = v
-    _save(f"clip_train_ws{world}", **flat)
+    _save(f"clip_train_ws{world}" + (f"g{group_size}" if group_size and group_size != world else ""), **flat)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["config", "heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "vit", "clip_glue", "dist1", "dist2"]
+    which = sys.argv[1:] or ["config", "heads", "retrieval", "miou", "interp_pe", "seg_block", "bert", "vit", "clip_glue", "dist1", "dist2", "dist4", "dist4g2"]
     torch.set_num_threads(4)
     _import_reference()
     for w in which:
         if w.startswith("dist"):
-            gold_dist(int(w[4:]))
+            ws, _, gs = w[4:].partition("g")
+            # dist1 / dist2: the world group handed to the loss directly; dist4: the reference's own group construction with
+            # group_size = world; dist4g2: two sub-groups of two ranks
+            gold_dist(int(ws), int(gs) if gs else (int(ws) if int(ws) >= 4 else None))
         else:
             globals()["gold_" + w]()

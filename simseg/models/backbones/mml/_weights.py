@@ -22,8 +22,14 @@ def _adapt(sd, module):
     sd = {k: v for k, v in sd.items() if not k.startswith(_HEAD_PREFIXES)}
     sd = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in sd.items()}       # BertForPreTraining-style prefixes
     # the original bert-base-uncased checkpoints name LayerNorm's parameters gamma / beta; HF's from_pretrained renames them on load
-    sd = {(k[:-len(".gamma")] + ".weight" if k.endswith(".gamma") else k[:-len(".beta")] + ".bias" if k.endswith(".beta") else k): v
-          for k, v in sd.items()}
+    # (LayerNorm modules only: timm's LayerScale parameters are called `ls1.gamma` / `ls2.gamma` and must keep their names)
+    def _ln(k):
+        if "LayerNorm." in k and k.endswith(".gamma"):
+            return k[:-len(".gamma")] + ".weight"
+        if "LayerNorm." in k and k.endswith(".beta"):
+            return k[:-len(".beta")] + ".bias"
+        return k
+    sd = {_ln(k): v for k, v in sd.items()}
     pe = sd.get("pos_embed")
     if pe is not None and hasattr(module, "pos_embed") and hasattr(module, "patch_embed") and pe.shape != module.pos_embed.shape:
         sd["pos_embed"] = interpolate_pos_embed(pe.float(), module)
@@ -37,6 +43,9 @@ def maybe_load_pretrained(module, tag):
         sd = _adapt(torch.load(path, map_location="cpu"), module)
         missing, unexpected = module.load_state_dict(sd, strict=False)
         unexpected = [k for k in unexpected if not k.endswith(_KNOWN_UNEXPECTED)]
+        # `embeddings.position_ids` is a persistent BUFFER of this tower (as in transformers 4.21.3); checkpoints written by later
+        # transformers versions and the original gamma / beta files do not carry it - its constructor value (arange) is the only one
+        missing = [k for k in missing if not k.endswith(_KNOWN_UNEXPECTED)]
         if missing:
             # a file that only partly matches would leave those tensors at their random / identity init while reporting "pretrained"
             raise KeyError(f"pretrained weights for {tag!r} ({path}) do not cover {len(missing)} tensors of the tower, e.g. "

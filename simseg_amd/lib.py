@@ -61,11 +61,12 @@ _HALF = threading.local()     # .seen: 16-bit flavour of the tensors handed to p
 
 
 def note_half(dtype):
-    """A call whose 16-bit tensors do not pass through ptr() (pointer tables): say which flavour they are."""
+    """A call whose 16-bit tensors do not pass through ptr() (pointer tables): say which flavour they are.  Both flavours are recorded
+    (bit 0 = bf16, bit 1 = fp16) so that call() can refuse a mix instead of silently reading one type as the other."""
     if dtype is torch.float16:
-        _HALF.seen = 2
-    elif dtype is torch.bfloat16 and getattr(_HALF, "seen", 0) != 2:
-        _HALF.seen = 1
+        _HALF.seen = getattr(_HALF, "seen", 0) | 2
+    elif dtype is torch.bfloat16:
+        _HALF.seen = getattr(_HALF, "seen", 0) | 1
 
 
 def ptr(t):
@@ -91,6 +92,11 @@ def call(name, *args):
     seen = getattr(_HALF, "seen", 0)
     if seen:
         _HALF.seen = 0
+        if seen == 3:
+            # either the arguments of this call mix the two 16-bit types, or an exception between a wrapper's ptr() calls and its call()
+            # left a selection behind: refuse loudly (the selection is cleared, so the next call starts clean)
+            raise RuntimeError(f"{name}: bf16 and fp16 tensors were handed to one call (or an earlier call failed half-way); "
+                               "dtype code 1 of the C ABI means ONE 16-bit type per call")
         if getattr(_HALF, "cur", 1) != seen:          # (thread-local on both sides: autograd's backward threads start at bf16 like the library)
             if lib.simseg_set_half_type(seen) != 0:
                 raise RuntimeError(lib.simseg_last_error().decode())

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .lib import call, note_half, ptr, stream
-from .towers import register_w16
+from .towers import drop_split_copy, register_w16
 
 CHUNK = 1 << 16
 RING = 4
@@ -112,6 +112,7 @@ class AdamW(torch.optim.Optimizer):
             plan["keepalive"] = grads        # the kernel reads them asynchronously
             for p in params:                 # same stream as the next forward: the copies are current when it runs
                 register_w16(p, self.state[p]["p16"])
+                drop_split_copy(p)           # the exact-mode split-bf16 copy of the OLD value (raw-pointer update: _version did not move)
 
     # ---- checkpoints in torch.optim.AdamW's layout ---------------------------------------------------------------------
     def state_dict(self):

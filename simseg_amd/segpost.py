@@ -187,6 +187,12 @@ class EvalPipeline:
             ev.record()
             if not self.pipelined:
                 self.last = self.finish(enc, *batch)
+                # the batch was allocated under the caller's stream and is read by kernels queued on this one: keep it (and the encoder's
+                # outputs) referenced until an event behind them has completed, as the pipelined path does - otherwise the caching
+                # allocator may hand those blocks to the caller's next host->device copy while they are still being read
+                done = torch.cuda.Event()
+                done.record()
+                self.retire.append((done, enc, batch))
                 return
         prev, self.pending = self.pending, (ev, enc, batch)
         if prev is not None:

@@ -28,6 +28,12 @@ def register_w16(param, w16):
     _W16[id(param)] = (weakref.ref(param), param._version, param.data_ptr(), w16)
 
 
+def drop_split_copy(param):
+    """Forget the split-bf16 (exact-mode evaluation) copy of a parameter the optimizer's kernel has just rewritten through raw pointers
+    (neither `_version` nor `data_ptr` moves, so `_wt_split`'s own check cannot see the update)."""
+    _W3.pop(id(param), None)
+
+
 def invalidate_weight_cache():
     """Drop every cached bf16 weight copy.  Needed only after writes torch cannot see (in-place ops on `param.data`, which
     carry their own version counter); load_state_dict / copy_ / optimizers / .to() are detected without it."""

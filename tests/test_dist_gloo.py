@@ -145,3 +145,123 @@ def test_gather_layer_matches_reference_two_ranks(world):
         mean = (np.array(out[0]["gsync"][0][k]) + np.array(out[1]["gsync"][0][k])) / 2
         for r in range(world):
             np.testing.assert_allclose(np.array(out[r]["gsync"][1][k]), mean, rtol=1e-6, atol=1e-7)
+
+
+# ---- four ranks: the whole-world loss and cfg.loss.group_size sub-groups (mml_loss.py:24-27) -------------------------------------------
+def _worker_groups(rank, world, port, q, group_size, fixture):
+    """The exchange step on `world` ranks with the loss gathered over sub-groups of `group_size` ranks: this repo's generate_local_groups
+    (host-by-host packing, new_group on every rank) + GatherLayer (all-gather forward, reduce-scatter backward over the SUB-group) around
+    the oracle's loss arithmetic, against what the REFERENCE's own generate_local_groups + GatherLayer + NCE produced in a 4-process gloo
+    run (oracle/make_golden.py dist4 / dist4g2)."""
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import simseg_ref as R
+    from simseg.utils import ENV, GatherLayer
+    from simseg.utils.dist import all_gather_group, generate_local_groups
+    ENV.rank, ENV.size, ENV.local_rank = rank, world, rank
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    group, grank = generate_local_groups(group_size)
+    res = {"group": (dist.get_world_size(group), grank, dist.get_process_group_ranks(group))}
+    f1 = torch.from_numpy(g[f"r{rank}.nce_f1"]).requires_grad_(True)
+    f2 = torch.from_numpy(g[f"r{rank}.nce_f2"]).requires_grad_(True)
+    ign = torch.from_numpy(g[f"r{rank}.nce_ign"])
+    temp = torch.tensor(0.02, requires_grad=True)
+    f2g = GatherLayer.apply(f2, group, grank)
+    ign_g = torch.cat(all_gather_group(ign, group))
+    loss, acc = R.nce_global(f1, f2g, temp, grank, ign, ign_g)
+    loss.backward()
+    res.update(loss=loss.item(), acc=acc.item(), g1=f1.grad.numpy(), g2=f2.grad.numpy(), gt=temp.grad.item(), rows=f2g.shape[0],
+               want_loss=float(g[f"r{rank}.nce_loss"]), want_acc=float(g[f"r{rank}.nce_acc"]), want_g1=g[f"r{rank}.nce_g1"],
+               want_g2=g[f"r{rank}.nce_g2"], want_gt=float(g[f"r{rank}.nce_gt"]))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("group_size,fixture", [(4, "clip_train_ws4"), (2, "clip_train_ws4g2")])
+def test_gather_layer_and_local_groups_match_reference_four_ranks(group_size, fixture):
+    world = 4
+    out = _spawn(_worker_groups, world, group_size, fixture)
+    for r in range(world):
+        o = out[r]
+        first = r // group_size * group_size
+        assert o["group"] == (group_size, r % group_size, list(range(first, first + group_size))), o["group"]
+        assert o["rows"] == 8 * group_size                       # the loss sees its sub-group's rows only
+        np.testing.assert_allclose(o["loss"], o["want_loss"], rtol=2e-5)
+        np.testing.assert_allclose(o["acc"], o["want_acc"], atol=1e-6)
+        np.testing.assert_allclose(o["g1"], o["want_g1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o["g2"], o["want_g2"], rtol=1e-4, atol=1e-6)     # summed over the sub-group's losses
+        np.testing.assert_allclose(o["gt"], o["want_gt"], rtol=1e-4)
+
+
+# ---- SURVEY.md section 4: the same global batch on 1 / 2 / 4 ranks gives the same loss and the same averaged gradients -------------------
+def _invariance_case():
+    gen = torch.Generator().manual_seed(17)
+    x1, x2 = torch.randn(8, 24, generator=gen), torch.randn(8, 24, generator=gen)
+    w1, w2 = torch.randn(16, 24, generator=gen) * 0.3, torch.randn(16, 24, generator=gen) * 0.3
+    return x1, x2, w1, w2
+
+
+def _invariance_step(x1, x2, w1, w2, temp, gather, rank):
+    from oracle import simseg_ref as R
+    e1 = torch.nn.functional.normalize(x1 @ w1.T, dim=-1)
+    e2 = torch.nn.functional.normalize(x2 @ w2.T, dim=-1)
+    l1, _ = R.nce_global(e1, gather(e2), temp, rank)
+    l2, _ = R.nce_global(e2, gather(e1), temp, rank)
+    return 0.5 * (l1 + l2)
+
+
+def _worker_invariance(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simseg.utils import ENV, GatherLayer
+    from simseg.utils.dist import generate_local_groups
+    ENV.rank, ENV.size, ENV.local_rank = rank, world, rank
+    group, grank = generate_local_groups(world)
+    x1, x2, w1, w2 = _invariance_case()
+    n = 8 // world
+    w1, w2 = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    temp = torch.tensor(0.05, requires_grad=True)
+    loss = _invariance_step(x1[rank * n:(rank + 1) * n], x2[rank * n:(rank + 1) * n], w1, w2, temp, lambda t: GatherLayer.apply(t, group, grank), grank)
+    loss.backward()
+    vals = [loss.detach().clone(), w1.grad, w2.grad, temp.grad]
+    for v in vals:                                               # what DDP / GradSync do with parameter gradients (core/hooks/dist.py:48-51)
+        dist.all_reduce(v)
+        v /= world
+    q.put((rank, [v.numpy() for v in vals]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_and_gradients_do_not_depend_on_the_number_of_ranks():
+    x1, x2, w1, w2 = _invariance_case()
+    w1, w2 = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    temp = torch.tensor(0.05, requires_grad=True)
+    loss = _invariance_step(x1, x2, w1, w2, temp, lambda t: t, 0)
+    loss.backward()
+    want = [loss.detach().numpy(), w1.grad.numpy(), w2.grad.numpy(), temp.grad.numpy()]
+    for world in (2, 4):
+        out = _spawn(_worker_invariance, world)
+        for r in range(world):
+            for got, ref in zip(out[r], want):
+                np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6, err_msg=f"world {world} rank {r}")

@@ -123,6 +123,88 @@ def test_two_ranks_match_reference_two_process_run(world):
             assert not bad, bad
 
 
+def _worker_groups(rank, world, port, backend, group_size, fixture, q):
+    """Four ranks, the loss gathered over sub-groups (cfg.loss.group_size, mml_loss.py:24-27): the product path end to end - this repo's
+    generate_local_groups, NCE module, GatherLayer over the SUB-group and the HIP loss kernels - in exact fp32 against the reference's
+    4-process run, then one whole forward/backward of the rank's batch."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if torch.cuda.device_count() >= world else 0), SIMSEG_AMD_COMPUTE="fp32")
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from simseg.utils import ENV
+        ENV.rank, ENV.size, ENV.local_rank = rank, world, dev.index
+        from test_gpu_model import _build
+        g = np.load(os.path.join(GOLD, fixture + ".npz"))
+
+        def golden(name):
+            return np.load(os.path.join(GOLD, name + ".npz"))
+
+        m = _build(golden, extra=[f"loss.group_size={group_size}"]).eval()
+        nce = m.loss
+        res = {"group": (dist.get_world_size(nce.group), nce.rank)}
+        f1 = torch.from_numpy(g[f"r{rank}.nce_f1"]).to(dev).requires_grad_(True)
+        f2 = torch.from_numpy(g[f"r{rank}.nce_f2"]).to(dev).requires_grad_(True)
+        ign = torch.from_numpy(g[f"r{rank}.nce_ign"]).to(dev)
+        loss, acc = nce(f1, f2, ignore_mask=ign)
+        loss.backward()
+        res["nce"] = dict(loss=loss.item(), acc=acc.item(), g1=f1.grad.cpu().numpy(), g2=f2.grad.cpu().numpy(), gt=nce.temperature.grad.item())
+        m.zero_grad(set_to_none=True)
+        batch = {k: torch.from_numpy(g[f"r{rank}.{k}"]).to(dev) for k in ("image", "input_ids", "attention_mask")}
+        loss_dict, a1, a2 = m(batch)                   # exact fp32 towers + prefetched sub-group gathers
+        loss_dict["nce_loss"].backward()
+        torch.cuda.synchronize()
+        params = dict(m.named_parameters())
+        grads = {}
+        for k in g.files:
+            if k.startswith(f"r{rank}.grad."):
+                name = k[len(f"r{rank}.grad."):]
+                v = params[name].grad.float().cpu().numpy()
+                grads[name] = v[:g[k].shape[0]] if v.ndim == 2 and v.shape != g[k].shape else v
+        res["step"] = dict(loss=loss_dict["nce_loss"].item(), a1=a1.item(), a2=a2.item(), grads=grads)
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("group_size,fixture", [(2, "clip_train_ws4g2"), (4, "clip_train_ws4")])
+def test_four_ranks_with_loss_sub_groups_match_reference(group_size, fixture):
+    world = 4
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, backend, group_size, fixture, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    for r in range(world):
+        assert out[r]["group"] == (group_size, r % group_size)
+        o = out[r]["nce"]
+        np.testing.assert_allclose(o["loss"], float(g[f"r{r}.nce_loss"]), rtol=2e-5)
+        np.testing.assert_allclose(o["acc"], float(g[f"r{r}.nce_acc"]), atol=1e-6)
+        np.testing.assert_allclose(o["g1"], g[f"r{r}.nce_g1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o["g2"], g[f"r{r}.nce_g2"], rtol=1e-4, atol=1e-6)      # summed over the sub-group's losses (reduce-scatter)
+        np.testing.assert_allclose(o["gt"], float(g[f"r{r}.nce_gt"]), rtol=1e-4)
+        s = out[r]["step"]
+        np.testing.assert_allclose(s["loss"], float(g[f"r{r}.loss"]), rtol=1e-4)
+        assert abs(s["a1"] - float(g[f"r{r}.i2t_acc"])) < 1e-6 and abs(s["a2"] - float(g[f"r{r}.t2i_acc"])) < 1e-6
+        for name, ours in s["grads"].items():           # exact fp32 kernels: every stored gradient against the REFERENCE's own
+            ref = g[f"r{r}.grad.{name}"]
+            err = float(np.abs(ours - ref).max()) / (float(np.abs(ref).max()) + 1e-30)
+            assert err < 2e-4, (r, name, err)
+
+
 def _worker_sync_and_retrieval(rank, world, port, backend, q):
     """(a) GradSync(overlap=True) with the towers on two streams == torch DDP's averaged gradients; (b) the multi-rank retrieval
     evaluation == the single-process one."""

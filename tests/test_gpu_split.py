@@ -83,6 +83,41 @@ def test_vit_tower_through_split_gemms_matches_fp32_kernels_and_oracle(monkeypat
     assert towers.SPLIT_CALLS[0] == n0
 
 
+def test_split_weight_copies_follow_the_optimizer(monkeypatch):
+    """train -> exact-mode eval -> train -> eval: simseg_amd.optim.AdamW rewrites the fp32 masters through raw pointers (no `_version`
+    bump), so the cached split-bf16 copies of the evaluation path must be dropped by the optimizer step; the second evaluation has to see
+    the UPDATED weights (round-3 advisor finding: it used the first evaluation's copies)."""
+    from simseg_amd import towers
+    from simseg_amd.nn import ViT
+    from simseg_amd.optim import AdamW
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    torch.manual_seed(3)
+    m = ViT("vit_test_patch16", 64).cuda()
+    opt = AdamW(m.parameters(), lr=5e-2, weight_decay=0.0)
+    x = torch.randn(64, 3, 64, 64, device="cuda")                 # 64 x 17 token rows
+
+    def evals():
+        m.eval()
+        with torch.no_grad():
+            monkeypatch.setattr(towers, "_SPLIT_FP32", "1")
+            n0 = towers.SPLIT_CALLS[0]
+            a = m(x)
+            assert towers.SPLIT_CALLS[0] > n0                     # the split path ran
+            monkeypatch.setattr(towers, "_SPLIT_FP32", "0")
+            b = m(x)                                              # fp32 kernels on the live masters
+        return a, b
+
+    a0, b0 = evals()
+    assert float((a0 - b0).abs().max()) < 2e-5 * float(b0.abs().max())
+    m.train()
+    monkeypatch.setattr(towers, "_SPLIT_FP32", "0")
+    m(x).square().mean().backward()
+    opt.step()
+    a1, b1 = evals()
+    assert float((b1 - b0).abs().max()) > 1e-2 * float(b0.abs().max())      # the step moved the weights
+    assert float((a1 - b1).abs().max()) < 2e-5 * float(b1.abs().max()), "the split path evaluated stale weights"
+
+
 @pytest.mark.parametrize("B,T,H", [(2, 1025, 12), (3, 325, 6), (2, 197, 4), (1, 64, 2), (1, 40, 1)])
 def test_attention_through_bf16_pieces_is_fp32_accurate(B, T, H):
     """simseg_attention_fwd_x3 against the fp64 softmax(Q K^T / 8) V, next to the fp32 MFMA kernel on the same inputs."""

@@ -211,6 +211,42 @@ def test_pretrained_tower_weights_resample_pos_embed_or_fail_loudly(tmp_path, mo
     assert np.allclose(interpolate_pos_embed(torch.from_numpy(ref["pe"]), fake).numpy(), ref["pe_18"], atol=1e-6)
 
 
+def test_pretrained_bert_with_original_gamma_beta_names_and_no_position_ids(tmp_path, monkeypatch):
+    """The original bert-base-uncased files name LayerNorm's parameters gamma / beta, prefix everything with `bert.`, carry pooler / cls
+    heads and (like checkpoints written by recent transformers) no `embeddings.position_ids` buffer: such a file must load with
+    `pretrained: True` (huggingface_builder.py:10-11 - from_pretrained renames on load), while a file that really misses a tensor still
+    fails; timm's LayerScale `ls1.gamma` keeps its name (only LayerNorm modules are renamed)."""
+    from simseg.models import BACKBONE
+    from simseg.models.backbones.mml._weights import _adapt
+    from simseg_amd.nn import Bert
+    argv = [a for a in TINY if "text_encoder.pretrained" not in a] + ["model.text_encoder.pretrained=True"]
+    cfg = _cfg("simseg.vit-s.yaml", argv)
+    monkeypatch.delenv("SIMSEG_ALLOW_RANDOM_INIT", raising=False)
+    monkeypatch.setenv("SIMSEG_PRETRAINED_DIR", str(tmp_path))
+    src = Bert("bert-test")
+    sd = {}
+    for k, v in src.state_dict().items():
+        if k.endswith("position_ids"):
+            continue
+        v = torch.randn_like(v) if v.is_floating_point() else v.clone()
+        if "LayerNorm." in k:
+            k = k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+        sd["bert." + k] = v
+    sd["bert.pooler.dense.weight"], sd["cls.predictions.bias"] = torch.zeros(4, 4), torch.zeros(4)
+    torch.save(sd, tmp_path / "bert-test.pth")
+    m = BACKBONE.get("huggingface_modelzoo")(cfg).model
+    assert torch.equal(m.embeddings.LayerNorm.weight.detach(), sd["bert.embeddings.LayerNorm.gamma"])
+    assert torch.equal(m.encoder.layer[1].output.LayerNorm.bias.detach(), sd["bert.encoder.layer.1.output.LayerNorm.beta"])
+    assert torch.equal(m.encoder.layer[0].attention.self.key.weight.detach(), sd["bert.encoder.layer.0.attention.self.key.weight"])
+    assert torch.equal(m.embeddings.position_ids, torch.arange(m.embeddings.position_ids.shape[1])[None])
+    del sd["bert.encoder.layer.1.intermediate.dense.bias"]
+    torch.save(sd, tmp_path / "bert-test.pth")
+    with pytest.raises(KeyError, match="do not cover 1 tensors"):
+        BACKBONE.get("huggingface_modelzoo")(cfg)
+    out = _adapt({"blocks.0.ls1.gamma": torch.ones(3), "blocks.0.norm1.weight": torch.ones(3)}, torch.nn.Identity())
+    assert set(out) == {"blocks.0.ls1.gamma", "blocks.0.norm1.weight"}
+
+
 def test_bert_qkv_parameters_are_packed_back_to_back():
     """HF names are kept (three Linear modules) but query / key / value live adjacent in one buffer, so the fused projection reads them
     in place; the packing survives dtype / device moves and in-place state-dict loads, and a broken packing is detected (-> concatenation)."""

@@ -114,19 +114,23 @@ def test_clip_glue(golden):
         torch.testing.assert_close(m.forward_text_project(t, tt(g["attention_mask"])), tt(g["txt_emb"]), rtol=1e-4, atol=2e-5)
 
 
-def _check_train(golden, world):
-    g = golden(f"clip_train_ws{world}")
+def _check_train(golden, world, group_size=None):
+    """group_size: cfg.loss.group_size sub-groups (mml_loss.py:24-27) - rank r exchanges embeddings with the ranks of its group only
+    (one host: consecutive ranks), its targets are indexed by its rank INSIDE the group."""
+    gs = group_size or world
+    g = golden(f"clip_train_ws{world}" + (f"g{gs}" if gs != world else ""))
     m = _ref_clip(golden("clip_glue"))
     embs = []
     for r in range(world):
         embs.append(m.embeddings(tt(g[f"r{r}.image"]), tt(g[f"r{r}.input_ids"]), tt(g[f"r{r}.attention_mask"])))
-    ig = torch.cat([e[0] for e in embs]); tg = torch.cat([e[1] for e in embs])
+    members = lambda r: list(range(r // gs * gs, r // gs * gs + gs))      # noqa: E731
     # reference semantics (GatherLayer.backward = all_reduce(SUM) then slice, utils/dist.py:347-354; DDP is not
     # wrapped in the fixture run): each rank's parameter grads come from its own loss, with embedding grads
     # summed over every rank's loss before flowing into this rank's towers.
     losses = []
     for r in range(world):
-        loss, a1, a2 = R.clip_loss(embs[r][0], embs[r][1], ig, tg, m.loss.temperature, r)
+        ig = torch.cat([embs[j][0] for j in members(r)]); tg = torch.cat([embs[j][1] for j in members(r)])
+        loss, a1, a2 = R.clip_loss(embs[r][0], embs[r][1], ig, tg, m.loss.temperature, r % gs)
         np.testing.assert_allclose(loss.item(), g[f"r{r}.loss"], rtol=2e-5)
         np.testing.assert_allclose(a1.item(), g[f"r{r}.i2t_acc"], atol=1e-6)
         np.testing.assert_allclose(a2.item(), g[f"r{r}.t2i_acc"], atol=1e-6)
@@ -139,6 +143,27 @@ def _check_train(golden, world):
             if k.startswith("r0.grad."):
                 name = k[len("r0.grad."):]
                 torch.testing.assert_close(params[name].grad, tt(g[k]), rtol=2e-3, atol=2e-6, msg=lambda s: name + s)
+    elif world >= 4:
+        # every rank's parameter gradients: the towers of rank r see d/d(emb_r) of the SUM of its group's losses (the all-reduce of the
+        # gathered gradient), the temperature only rank r's own loss (it is not gathered)
+        params = dict(m.named_parameters())
+        for r in range(world):
+            mine = m.embeddings(tt(g[f"r{r}.image"]), tt(g[f"r{r}.input_ids"]), tt(g[f"r{r}.attention_mask"]))
+            e = {j: (mine if j == r else (embs[j][0].detach(), embs[j][1].detach())) for j in members(r)}
+            ig = torch.cat([e[j][0] for j in members(r)]); tg = torch.cat([e[j][1] for j in members(r)])
+            tot = 0
+            for j in members(r):
+                temp = m.loss.temperature if j == r else m.loss.temperature.detach()
+                tot = tot + R.clip_loss(e[j][0], e[j][1], ig, tg, temp, j % gs)[0]
+            m.zero_grad()
+            tot.backward()
+            for k in g.files:
+                if k.startswith(f"r{r}.grad."):
+                    name = k[len(f"r{r}.grad."):]
+                    want = tt(g[k])
+                    got = params[name].grad
+                    got = got[:want.shape[0]] if got.dim() == 2 and got.shape != want.shape else got      # (large matrices: first 16 rows stored)
+                    torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-6, msg=lambda s: f"rank {r} {name}" + s)
     # pure-loss fixture with ignore_mask (mml_loss.py:70-71,89-93)
     f1 = [tt(g[f"r{r}.nce_f1"]).requires_grad_(True) for r in range(world)]
     f2 = [tt(g[f"r{r}.nce_f2"]).requires_grad_(True) for r in range(world)]
@@ -147,7 +172,7 @@ def _check_train(golden, world):
     tot = 0
     ls = []
     for r in range(world):
-        l, acc = R.nce_global(f1[r], torch.cat(f2), temp, r, ign[r], torch.cat(ign))
+        l, acc = R.nce_global(f1[r], torch.cat([f2[j] for j in members(r)]), temp, r % gs, ign[r], torch.cat([ign[j] for j in members(r)]))
         np.testing.assert_allclose(l.item(), g[f"r{r}.nce_loss"], rtol=2e-5)
         np.testing.assert_allclose(acc.item(), g[f"r{r}.nce_acc"], atol=1e-6)
         ls.append(l)
@@ -158,7 +183,7 @@ def _check_train(golden, world):
     # per-rank temperature grad comes from that rank's own loss only
     for r in range(world):
         temp2 = torch.tensor(0.02, requires_grad=True)
-        l, _ = R.nce_global(f1[r].detach(), torch.cat(f2).detach(), temp2, r, ign[r], torch.cat(ign))
+        l, _ = R.nce_global(f1[r].detach(), torch.cat([f2[j] for j in members(r)]).detach(), temp2, r % gs, ign[r], torch.cat([ign[j] for j in members(r)]))
         l.backward()
         np.testing.assert_allclose(temp2.grad.item(), g[f"r{r}.nce_gt"], rtol=1e-4)
 
@@ -169,3 +194,11 @@ def test_clip_train_ws1(golden):
 
 def test_clip_train_ws2(golden):
     _check_train(golden, 2)
+
+
+def test_clip_train_ws4(golden):
+    _check_train(golden, 4)
+
+
+def test_clip_train_ws4_groups_of_two(golden):
+    _check_train(golden, 4, group_size=2)
