@@ -77,7 +77,9 @@ def synthetic_batch(B, img, L, vocab, seed, device):
     ids = ids * mask
     ids[:, 0] = 101
     ids[torch.arange(B), lens - 1] = 102
-    return {"image": image.to(device), "input_ids": ids.to(device), "attention_mask": mask.to(device)}
+    # caption_lengths: the captions' token counts as HOST numbers, as a loader has them from its tokenizer before the host->device copy
+    # (optional batch key of this package: the text tower then sizes its packed rows without reading the device - simseg_amd/towers.py)
+    return {"image": image.to(device), "input_ids": ids.to(device), "attention_mask": mask.to(device), "caption_lengths": lens.clone()}
 
 
 def _cpu_threads():
@@ -563,6 +565,7 @@ def main():
     # step (a clone, as a loader delivers them), so whatever the model derives from a mask - towers.ragged_maps with its host read of
     # the real-token count, clip_k_to_shortest - is rebuilt inside the timed region every step instead of being cached on the tensor
     NB = max(1, args.batches)
+    HOST_LENGTHS = os.environ.get("SIMSEG_BENCH_HOST_LENGTHS", "1") != "0"      # (0: the model reads the real-token count back from the device)
     batches = [synthetic_batch(B, args.img, L, 30522, 1000 + rank + 100 * i, dev) for i in range(NB)]
     step_no = [0]
     log(f"model and {NB} batches on device")
@@ -570,7 +573,10 @@ def main():
     def next_batch():
         b = batches[step_no[0] % NB]
         step_no[0] += 1
-        return {"image": b["image"], "input_ids": b["input_ids"].clone(), "attention_mask": b["attention_mask"].clone()}
+        out = {"image": b["image"], "input_ids": b["input_ids"].clone(), "attention_mask": b["attention_mask"].clone()}
+        if HOST_LENGTHS:
+            out["caption_lengths"] = b["caption_lengths"]
+        return out
 
     def step():
         opt.zero_grad(set_to_none=(world == 1 or sync is not None))     # under DDP the grads are views into the all-reduce buckets
@@ -763,6 +769,8 @@ def main():
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
                        "process_group": pg_info, "batches_rotated": NB,
+                       "caption_lengths": ("host-side token counts travel with the batch (no host read in the step)" if HOST_LENGTHS
+                                           else "derived from the device mask (one host read per step)"),
                        "gradient_sync": ("none" if world == 1 else (f"simseg_amd.parallel.GradSync ({dp})" if sync is not None else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",

@@ -214,6 +214,15 @@ int simseg_attention_fwd_x3(const void* qkv3, int64_t plane_elems, float* out, i
 /* dst[i,:] = src[idx[i],:] (idx[i] < 0: a zero row); rows of row_bytes (a multiple of 16) bytes, any dtype.  Drops / restores the padded
  * token rows of ragged caption batches around the text tower's GEMMs (HF BertModel computes them: huggingface_builder.py:16-17). */
 int simseg_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n, int64_t row_bytes, void* stream);
+/* Row maps of a ragged caption batch from its 0/1 attention mask [B, L] (int64, as the reference's tokenizer delivers it:
+ * simseg/datasets/clip/clip_dataset.py:127-133), in one launch and without a host read: idx int32 [cap] = flat positions b*L+l of the real
+ * tokens in raster order, then -1 up to the next multiple of `multiple` (or cap); inv int32 [B*L] = packed row of every position (-1 at
+ * padded positions); row_start int32 [B+1]; info int32 [4] = {real tokens, 1 if a sequence has a real token behind a padded one,
+ * 1 if they did not fit cap rows or differ from `expect` (>= 0: the count the caller sized its buffers for, e.g. from the loader's
+ * caption lengths; -1: unknown), rows of idx written}.  What the text tower needs to skip the padded token rows HF's BertModel computes
+ * (huggingface_builder.py:16-17) - replaces ~15 torch index kernels and two host reads per step.  B <= 8192. */
+int simseg_ragged_maps(const int64_t* mask, int64_t B, int64_t L, int64_t multiple, int64_t cap, int64_t expect, int32_t* idx, int32_t* inv,
+                       int32_t* row_start, int32_t* info, void* stream);
 /* g[i] = keep(seed, i) ? g[i] / (1-p) : 0 -- regenerates the forward dropout mask of simseg_gemm for the backward. */
 int simseg_dropout_apply(void* g, int dtype, int64_t n, uint64_t seed, float p, void* stream);
 

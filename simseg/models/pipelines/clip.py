@@ -103,6 +103,9 @@ class CLIPModel(nn.Module):
         if embeddings == "text":
             return self.forward_text_feature(batch["input_ids"], batch["attention_mask"])
         image, ids, mask = batch["image"], batch["input_ids"], batch["attention_mask"]
+        # optional, beyond the reference's batch keys: the captions' token counts as HOST numbers (what the tokenizer returned before the
+        # host->device copy).  With them the text tower sizes its packed rows without reading anything back from the GPU.
+        lengths = batch.get("caption_lengths") if isinstance(batch, dict) else None
         discard_prefetched(logger.warning)           # gathers of an earlier step that never reached the loss
         if image.is_cuda and _two_streams_ok():
             # The two towers are independent until the loss: the text tower runs on a second HIP stream so that its kernels
@@ -114,7 +117,7 @@ class CLIPModel(nn.Module):
             # (which tower is enqueued first makes no measurable difference: 126.2 vs 126.4 ms/step)
             img = self.forward_image_project(self.forward_image_feature(image))
             self._prefetch(img, embeddings)          # the image embeddings travel while the text tower is still computing
-            with torch.cuda.stream(side), packed_text():
+            with torch.cuda.stream(side), packed_text(lengths):
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
                 self._prefetch(txt, embeddings)
             main.wait_stream(side)
@@ -129,7 +132,7 @@ class CLIPModel(nn.Module):
         else:
             img = self.forward_image_project(self.forward_image_feature(image))
             self._prefetch(img, embeddings)
-            with packed_text():      # only the masked pooling reads the text tower's output here: padded token rows are not computed
+            with packed_text(lengths):      # only the masked pooling reads the text tower's output here: padded token rows are not computed
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
         if embeddings == "all":
             return [img, txt]

@@ -328,6 +328,21 @@ def transpose_f32(x2d):
     return out
 
 
+def ragged_maps(mask, multiple, cap, expect=-1):
+    """(idx int32 [cap], inv int32 [B*L], row_start int32 [B+1], info int32 [4]) of a [B, L] int64 0/1 mask - include/simseg_hip.h."""
+    require_gpu(mask)
+    if mask.dtype != torch.int64 or mask.dim() != 2:
+        raise TypeError("ragged_maps: int64 [B, L] mask")
+    B, L = mask.shape
+    dev = mask.device
+    idx = torch.empty(cap, device=dev, dtype=torch.int32)
+    inv = torch.empty(B * L, device=dev, dtype=torch.int32)
+    row_start = torch.empty(B + 1, device=dev, dtype=torch.int32)
+    info = torch.empty(4, device=dev, dtype=torch.int32)
+    call("simseg_ragged_maps", ptr(_c(mask)), B, L, int(multiple), int(cap), int(expect), ptr(idx), ptr(inv), ptr(row_start), ptr(info), stream())
+    return idx, inv, row_start, info
+
+
 def gather_rows(src2d, idx, out=None):
     """out[i] = src2d[idx[i]] (zero row where idx[i] < 0).  idx int32 on the device."""
     require_gpu(src2d, idx)

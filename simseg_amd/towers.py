@@ -551,13 +551,37 @@ class RowMapFn(Function):
         return ops.gather_rows(dy.contiguous(), bwd_map), None, None
 
 
-def ragged_maps(mask, multiple=256):
-    """(idx [Np] flat positions of the real tokens, inv [B*L] packed row of every position or -1, number of real tokens), maps int32, for
-    a [B, L] 0/1 mask.  idx is padded with -1 (zero rows, which receive zero gradients and are never put back) to a multiple of the GEMM
-    tile height: every row tile is a full tile (fast epilogues) and the weight-gradient contraction length stays a multiple of 64."""
-    cached = getattr(mask, "_simseg_ragged", None)      # (the count of real tokens needs a host read: once per mask tensor, not per layer / step)
-    if cached is not None and cached[0] == mask._version and cached[1] == multiple:
-        return cached[2]
+class RaggedPlan:
+    """Everything the text tower derives from an attention mask: idx [Np] (flat positions of the real tokens, -1 padded to a multiple of the
+    GEMM tile height: every row tile is full and the weight-gradient contraction length stays a multiple of 64), inv [B*L] (packed row of
+    every position, -1 at padded positions), nv (number of real tokens), cu (int32 [B+1] first packed row of every sequence, or None when
+    a mask has a hole - a real token behind a padded one - AND that is known: see ragged_plan)."""
+    __slots__ = ("idx", "inv", "nv", "cu")
+
+    def __init__(self, idx, inv, nv, cu):
+        self.idx, self.inv, self.nv, self.cu = idx, inv, nv, cu
+
+
+_RAGGED_KERNEL = os.environ.get("SIMSEG_AMD_RAGGED_KERNEL", "1") != "0"      # (A/B switch: 0 = the round-3 torch index ops with their two host reads)
+_LENGTH_CHECKS = []       # (event, pinned info copy, what) of plans sized from host-side caption lengths: verified one step late, without a sync
+
+
+_PINNED_INFO = []         # recycled pinned int32[4] buffers (pinning memory is a driver call: not once per step)
+
+
+def _poll_length_checks(block=False):
+    while _LENGTH_CHECKS and (block or len(_LENGTH_CHECKS) > 8 or _LENGTH_CHECKS[0][0].query()):
+        ev, info, what = _LENGTH_CHECKS.pop(0)
+        ev.synchronize()
+        _PINNED_INFO.append(info)
+        if int(info[2]):
+            _LENGTH_CHECKS.clear()
+            raise RuntimeError(f"caption_lengths do not describe the attention_mask of an earlier batch ({what}: the mask has {int(info[0])} real "
+                               "tokens): the text tower of that step ran on the wrong rows")
+
+
+def _plan_torch(mask, multiple):
+    """The maps with torch index ops (CPU tensors in the host-logic tests, batches of more than 8192 sequences): two host reads."""
     flat = mask.reshape(-1) != 0
     idx = flat.nonzero().flatten().to(torch.int32)
     nv = idx.numel()
@@ -566,34 +590,67 @@ def ragged_maps(mask, multiple=256):
     pad = (-nv) % multiple
     if pad and nv + pad < flat.numel():
         idx = torch.cat([idx, torch.full((pad,), -1, device=mask.device, dtype=torch.int32)])
-    try:
-        mask._simseg_ragged = (mask._version, multiple, (idx, inv, nv))
-    except Exception:       # noqa: BLE001  (a tensor subclass without attribute storage)
-        pass
-    return idx, inv, nv
-
-
-def ragged_rows(mask):
-    """int32 [B+1] first packed row of every sequence (the packed order of ragged_maps keeps a sequence's real tokens together), or None
-    when some mask has a hole - a real token behind a masked one.  The attention kernels then take the packed rows directly
-    (simseg_attention_fwd_rows): no round trip through the dense [B, L] layout.  For prefix masks - every caption the reference's
-    tokenizer produces - a token's index inside its packed sequence equals its position, so the dropout hash drops the same
-    probabilities as the dense path; with holes the packed path would still be the same function but not the same random mask, so the
-    dense path stays.  One more host read per mask tensor (cached on it like the maps)."""
-    cached = getattr(mask, "_simseg_rows", None)
-    if cached is not None and cached[0] == mask._version:
-        return cached[1]
     real = mask != 0
     lens = real.sum(1)
     holes = (real & (torch.arange(mask.shape[1], device=mask.device)[None] >= lens[:, None])).any()
     cu = torch.zeros(mask.shape[0] + 1, device=mask.device, dtype=torch.int32)
     cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
-    out = None if bool(holes) else cu
+    return RaggedPlan(idx, inv, nv, None if bool(holes) else cu)
+
+
+def ragged_plan(mask, multiple=256, lengths=None):
+    """RaggedPlan of a [B, L] 0/1 mask, cached on the mask tensor (per version).  On the GPU ONE kernel builds all of it
+    (ops.ragged_maps).  `lengths`: the captions' token counts as HOST numbers (a sequence / CPU tensor of B ints - a loader has them
+    before the host->device copy): the packed row count is then known without reading anything back, and the step has no host
+    synchronisation left in front of the loss.  The kernel still builds the maps from the device mask; its own count is compared with
+    sum(lengths) on the device and checked one step late (RuntimeError then).  Without lengths the count (and the hole flag) are read
+    back: one host read per mask tensor."""
+    cached = getattr(mask, "_simseg_ragged", None)
+    if cached is not None and cached[0] == mask._version and cached[1] == multiple:
+        return cached[2]
+    B, L = mask.shape
+    if not (mask.is_cuda and _RAGGED_KERNEL and B <= 8192 and mask.dtype == torch.int64 and mask.is_contiguous()):
+        plan = _plan_torch(mask, multiple)
+    else:
+        _poll_length_checks()
+        if lengths is not None:
+            nv = int(sum(int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)))
+            if len(lengths) != B or nv < 0 or nv > B * L:
+                raise ValueError(f"caption_lengths: {len(lengths)} entries summing to {nv} for a [{B}, {L}] mask")
+            np_ = nv + (-nv) % multiple
+            cap = np_ if np_ < B * L else nv
+            idx, inv, cu, info = ops.ragged_maps(mask, multiple, max(cap, 1), expect=nv)
+            host = _PINNED_INFO.pop() if _PINNED_INFO else torch.empty(4, dtype=torch.int32).pin_memory()
+            host.copy_(info, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _LENGTH_CHECKS.append((ev, host, f"{B} captions, lengths summing to {nv}"))
+            plan = RaggedPlan(idx[:cap], inv, nv, cu)      # (a hole does not matter to the packed attention: a sequence's real tokens are
+                                                            #  contiguous rows either way; only the dropout hash would index them differently)
+        else:
+            idx, inv, cu, info = ops.ragged_maps(mask, multiple, B * L)
+            nv, holes, _, _ = info.tolist()                 # the one host read
+            np_ = nv + (-nv) % multiple                     # (no tile padding when the padded rows would not be fewer than the dense ones)
+            plan = RaggedPlan(idx[:np_ if np_ < B * L else nv], inv, nv, None if holes else cu)
     try:
-        mask._simseg_rows = (mask._version, out)
-    except Exception:       # noqa: BLE001
+        mask._simseg_ragged = (mask._version, multiple, plan)
+    except Exception:       # noqa: BLE001  (a tensor subclass without attribute storage)
         pass
-    return out
+    return plan
+
+
+def ragged_maps(mask, multiple=256):
+    """(idx, inv, number of real tokens) - see RaggedPlan."""
+    p = ragged_plan(mask, multiple)
+    return p.idx, p.inv, p.nv
+
+
+def ragged_rows(mask):
+    """int32 [B+1] first packed row of every sequence (the packed order keeps a sequence's real tokens together), or None when some mask
+    has a hole.  The attention kernels then take the packed rows directly (simseg_attention_fwd_rows): no round trip through the dense
+    [B, L] layout.  For prefix masks - every caption the reference's tokenizer produces - a token's index inside its packed sequence
+    equals its position, so the dropout hash drops the same probabilities as the dense path."""
+    return ragged_plan(mask).cu
 
 
 _PACKED_ATTN = os.environ.get("SIMSEG_AMD_PACKED_ATTN", "1") != "0"      # (A/B switch: attention on the packed rows)
@@ -708,18 +765,20 @@ class BertLayerFn(_GradAwareFn):
 # tower therefore runs its GEMMs, LayerNorms and dropout on the real tokens only and returns zeros at the padded positions; loss,
 # accuracies and every parameter gradient are those of the dense computation.  The plain `forward_text_feature` API stays dense, so its
 # [B, L, 768] output equals the reference's at every position.  SIMSEG_AMD_PACKED_TEXT=0 switches the packing off.
-_PACK_TEXT = [False]
+_PACK_TEXT = [False, None]       # [pack the ragged batch?, host-side caption lengths of the batch being encoded (or None)]
 _SKIP_PAD = os.environ.get("SIMSEG_AMD_SKIP_PAD_ROWS", "1") != "0"      # (A/B switch: attention kernels on the effective lengths)
 
 
 @contextlib.contextmanager
-def packed_text():
-    prev = _PACK_TEXT[0]
+def packed_text(lengths=None):
+    """lengths: the batch's caption token counts as host numbers (batch["caption_lengths"], optional) - see ragged_plan."""
+    prev = list(_PACK_TEXT)
     _PACK_TEXT[0] = os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0"
+    _PACK_TEXT[1] = lengths
     try:
         yield
     finally:
-        _PACK_TEXT[0] = prev
+        _PACK_TEXT[:] = prev
 
 
 def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
@@ -736,13 +795,15 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
     idx = inv = cu = None
     nv = 0
     if _PACK_TEXT[0] and x.is_cuda:
-        idx, inv, nv = ragged_maps(mask)
+        lengths = _PACK_TEXT[1]
+        plan = ragged_plan(mask, lengths=lengths if (lengths is not None and len(lengths) == B) else None)
+        idx, inv, nv = plan.idx, plan.inv, plan.nv
         if nv == 0 or idx.numel() >= B * L:
             idx = inv = None                                        # nothing to drop
         else:
             x = RowMapFn.apply(x.view(-1, D), idx, inv)             # [Nv, D]
             if _PACKED_ATTN and adt != F32 and L <= 256:
-                cu = ragged_rows(mask)                              # None: a mask with a hole - attention through the dense layout
+                cu = plan.cu                                        # None: a mask with a hole - attention through the dense layout
     for i, lyr in enumerate(m.encoder.layer):
         a, s = lyr.attention, lyr.attention.self
         x = BertLayerFn.apply(x, mask, m.num_heads, adt, p_h, seed + 16 * (i + 1),

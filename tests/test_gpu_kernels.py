@@ -964,3 +964,47 @@ def test_gemm_saved_derivative_as_tile_blocked_image(ops, M, N, K, variant):
         ops.set_gemm_variant(0)
     with pytest.raises(RuntimeError, match="act 5"):
         ops.gemm(a[:M - 8], b, bias=bias, act=5, aux_out=d_blk[:M - 8])
+
+
+# ---- ragged caption batches: the row maps of the packed text tower, built by one kernel (round 4) ---------------------------------------
+@pytest.mark.parametrize("B,L,kind", [(6, 11, "holes"), (512, 77, "prefix"), (2048, 25, "prefix"), (37, 200, "holes"), (1, 5, "prefix"),
+                                      (1500, 3, "empty_rows"), (8, 64, "full")])
+def test_ragged_maps_kernel_equals_the_index_ops(B, L, kind):
+    from simseg_amd import towers
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    if kind == "empty_rows":
+        lens[::7] = 0
+    if kind == "full":
+        lens[:] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).long()
+    if kind == "holes":
+        mask = mask * (torch.rand(B, L, generator=g) > 0.2).long()
+    want = towers._plan_torch(mask, 256)
+    m = mask.cuda()
+    got = towers.ragged_plan(m, 256)                           # count + hole flag read back
+    assert got.nv == want.nv and torch.equal(got.idx.cpu(), want.idx) and torch.equal(got.inv.cpu(), want.inv)
+    assert (got.cu is None) == (want.cu is None)
+    if want.cu is not None:
+        assert torch.equal(got.cu.cpu(), want.cu)
+    assert towers.ragged_plan(m, 256) is got                   # cached on the tensor
+    m2 = mask.cuda()
+    host_lens = mask.sum(1)                                    # what a loader knows before the host->device copy
+    got2 = towers.ragged_plan(m2, 256, lengths=host_lens)      # nothing read back
+    assert got2.nv == want.nv and torch.equal(got2.idx.cpu(), want.idx) and torch.equal(got2.inv.cpu(), want.inv)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(host_lens, 0).to(torch.int32)
+    assert torch.equal(got2.cu.cpu(), cu)
+    towers._poll_length_checks(block=True)                     # the deferred comparison with the device count: clean
+
+
+def test_ragged_maps_wrong_host_lengths_are_reported_one_step_late():
+    from simseg_amd import towers
+    towers._poll_length_checks(block=True)
+    mask = (torch.arange(20)[None] < torch.tensor([5, 20, 1, 9])[:, None]).long().cuda()
+    towers.ragged_plan(mask, 8, lengths=[5, 20, 1, 8])          # one token short: sized without a read, so it cannot fail here
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="caption_lengths do not describe the attention_mask"):
+        towers.ragged_plan(torch.ones(2, 4, dtype=torch.long).cuda(), 8, lengths=[4, 4])
+    with pytest.raises(ValueError):
+        towers.ragged_plan(torch.ones(2, 4, dtype=torch.long).cuda(), 8, lengths=[4])

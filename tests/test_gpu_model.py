@@ -261,6 +261,38 @@ def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monke
     assert worst < 1e-4
 
 
+def test_training_step_with_host_caption_lengths_has_no_host_synchronisation(golden, monkeypatch):
+    """batch["caption_lengths"] (host numbers, what a loader's tokenizer returned): the text tower sizes its packed rows from them, one
+    kernel builds the row maps, and NOTHING in forward + loss + backward reads the device - asserted with torch's sync-debug mode (nonzero /
+    item / cpu raise).  Loss and gradients equal those of the same step without the lengths (count read back)."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", "1")
+    from simseg_amd import towers
+    g = golden("clip_train_ws1")
+    res = []
+    for with_lengths in (False, True):
+        m = _build(golden).eval()                       # (eval: no dropout, so the two runs are the same function)
+        batch = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+        if with_lengths:
+            batch["caption_lengths"] = tt(g["r0.attention_mask"]).sum(1)
+        m(batch)[0]["nce_loss"].backward()              # warm-up: weight copies, side stream
+        m.zero_grad(set_to_none=True)
+        batch = {k: (v.clone() if v.is_cuda else v) for k, v in batch.items()}      # fresh tensors: nothing cached on the mask
+        torch.cuda.synchronize()
+        if with_lengths:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            loss_dict, a1, a2 = m(batch)
+            loss_dict["nce_loss"].backward()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        res.append((loss_dict["nce_loss"].item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    towers._poll_length_checks(block=True)
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    for n, gd in res[0][1].items():          # (split-K atomics: the accumulation order of a weight gradient is not reproducible to the bit)
+        assert float((gd - res[1][1][n]).abs().max()) <= 1e-3 * float(gd.abs().max()) + 1e-12, n
+
+
 def test_packed_text_tower_equals_dense(golden, monkeypatch):
     """Ragged captions: inside CLIPModel.forward the text tower drops the padded token rows (GEMMs / LayerNorms on the real tokens only,
     the attention kernels on the dense layout with zero rows put back).  Loss, accuracies and every parameter gradient equal those of the
@@ -276,11 +308,11 @@ def test_packed_text_tower_equals_dense(golden, monkeypatch):
         m = _build(golden)
         m.eval()
         calls = []
-        orig = towers.ragged_maps
-        monkeypatch.setattr(towers, "ragged_maps", lambda mask: (calls.append(1), orig(mask))[1])
+        orig = towers.ragged_plan
+        monkeypatch.setattr(towers, "ragged_plan", lambda mask, *a, **k: (calls.append(1), orig(mask, *a, **k))[1])
         loss_dict, a1, a2 = m(batch)
         loss_dict["nce_loss"].backward()
-        monkeypatch.setattr(towers, "ragged_maps", orig)
+        monkeypatch.setattr(towers, "ragged_plan", orig)
         assert len(calls) == (1 if packed == "1" else 0)                                       # the packed path is the one that ran
         res[packed] = (loss_dict["nce_loss"].item(), a1.item(), a2.item(), {n: p.grad.clone() for n, p in m.named_parameters()})
         with torch.no_grad():

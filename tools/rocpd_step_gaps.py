@@ -15,7 +15,13 @@ def main(path, min_us=20.0):
     adam = [i for i, r in enumerate(rows) if "adamw" in r[2]]
     if len(adam) < 3:
         print("fewer than three optimizer launches in the trace"); return
-    lo, hi = adam[-2], adam[-1]
+    # the step to show: the SHORTEST interval between two consecutive optimizer launches (bench.py runs further legs after the timed
+    # steps - padded captions, the instrumented single-stream step - whose intervals contain host-side synchronisations), or the one
+    # whose index is given as the third argument
+    spans = [(rows[adam[i + 1]][1] - rows[adam[i]][1], i) for i in range(len(adam) - 1)]
+    pick = int(sys.argv[3]) if len(sys.argv) > 3 else min(spans)[1]
+    print("intervals between optimizer launches (ms): " + " ".join(f"{s_ / 1e6:.1f}" for s_, _ in spans) + f"   -> showing #{pick}")
+    lo, hi = adam[pick], adam[pick + 1]
     step = rows[lo:hi + 1]           # from the previous step's AdamW to this step's
     short = lambda n: re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", re.sub(r"^_ZN2at6native\d*", "at::", n or ""))[:70]
     t0 = step[0][1]
