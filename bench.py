@@ -647,7 +647,8 @@ def main():
         os.environ["SIMSEG_AMD_COMPUTE"] = "fp16"
         opt.half_dtype = torch.float16            # the optimizer kernel's 16-bit weight copies follow the compute type
         opt._plans.clear()
-        scaler = torch.amp.GradScaler("cuda")     # torch's defaults, as the reference constructs it: scale 65536, back-off 0.5, growth every 2000 clean steps
+        from simseg_amd.optim import GradScaler
+        scaler = GradScaler("cuda")     # torch.amp.GradScaler (its defaults, as the reference constructs it: scale 65536, back-off 0.5, growth every 2000 clean steps) with this package's one-kernel overflow check
         try:
             def step16():
                 opt.zero_grad(set_to_none=True)
@@ -658,15 +659,15 @@ def main():
             for _ in range(max(3, args.warmup)):
                 step16()
             torch.cuda.synchronize()
-            skipped0 = opt._step
+            skipped0 = opt.steps_taken()
             t2 = time.perf_counter()
             for _ in range(args.steps):
                 step16()
             torch.cuda.synchronize()
             el3 = time.perf_counter() - t2
             fp16_amp = {"pairs_per_s": round(B * args.steps / el3, 2), "ms_per_step": round(1e3 * el3 / args.steps, 3),
-                        "loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt._step - skipped0, "steps": args.steps,
-                        "note": "torch.amp.GradScaler live: scaled backward, unscale + inf check (one host read per step), skipped steps on overflow"}
+                        "loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt.steps_taken() - skipped0, "steps": args.steps,
+                        "note": "GradScaler live: scaled backward; overflow check = one read-only kernel, unscale + skip decision inside the AdamW kernel on the device (no host read in the step)"}
         finally:
             os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
             opt.half_dtype = torch.bfloat16

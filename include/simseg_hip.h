@@ -198,6 +198,21 @@ int simseg_adamw_multi_step(const void* table, const int64_t* sizes, const int32
                             int64_t n_chunks, int chunk, float beta1, float beta2, float eps, int64_t step, float grad_scale,
                             void* stream);
 
+/* The same launch inside the reference's fp16 AMP iteration (clip_runner.py:226-230; core/hooks/optimizer.py:73-82: scaler.scale(loss)
+ * .backward(), scaler.step(optimizer), scaler.update()) WITHOUT the host read torch's scaler.step makes for an optimizer that cannot skip
+ * a step by itself: loss_scale / found_inf are torch.amp.GradScaler's device tensors (its `optimizer.grad_scale` / `optimizer.found_inf`
+ * contract; either may be null).  Gradients are used as g * grad_scale / loss_scale[0]; when found_inf[0] != 0 nothing is updated.  The
+ * count of steps actually taken lives on the device: step_in[0] is read, step_out[0] = step_in[0] + (skipped ? 0 : 1) is written (two
+ * distinct slots) and supplies the bias corrections. */
+int simseg_adamw_multi_step_amp(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
+                                int64_t n_chunks, int chunk, float beta1, float beta2, float eps, float grad_scale,
+                                const float* loss_scale, const float* found_inf, const float* step_in, float* step_out, void* stream);
+/* found_inf[0] = 1 if any gradient element addressed by the table (same layout as above; only the g pointers are read) is inf / nan,
+ * else unchanged: GradScaler's overflow check (torch._amp_foreach_non_finite_check_and_unscale_ with inverse scale 1) as one read-only
+ * launch; the unscaling rides on simseg_adamw_multi_step_amp. */
+int simseg_grads_nonfinite(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off, int64_t n_chunks,
+                           int chunk, float* found_inf, void* stream);
+
 int simseg_cast(const void* in, void* out, int64_t n, int to_bf16, void* stream);
 int simseg_transpose_f32(const float* in, float* out, int64_t R, int64_t C, void* stream);
 /* fp32 [rows, K] (row stride ld_in) -> bf16 [rows, 6 K]: the three round-to-nearest bf16 pieces hi / mid / lo of every element

@@ -857,9 +857,13 @@ struct PPFrag {
 // bias / GELU run on the accumulators in MFMA layout (a lane owns ONE column: the bias is a scalar per lane), pairs of rows are packed to
 // bf16, staged TRANSPOSED ([column][row], 8-byte writes) in the wave's 4608-byte scratch `tl` and read back through ds_read_b64_tr_b16, which
 // hands every lane 4 consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per 32x64 block.
-// A4 = false: an instantiation without the times-saved-derivative branch (its 32 column-sum partials and operand sets set the kernel's
-// register high-water mark: with them compiled in, state that lives across the K loop is parked in scratch around EVERY tile)
-template <bool A4 = true>
+// EK = the epilogue kinds compiled into an instantiation beyond the plain ones (act 0 / 1 / 3 with row-major tensors): 0 = none, 1 = times the
+// saved derivative, row-major (act 4), 2 = GELU with the derivative saved as the tile-blocked accumulator image (act 5), 3 = times that image
+// (act 6).  Each of the three sets the kernel's register high-water mark (32 column-sum partials and two operand sets for 1; prefetched 16-register
+// operand sets for 3; a second converted accumulator block for 2): compiled into EVERY bf16-output kernel, state that lives across the K loop is
+// parked in scratch around every tile of every launch (round 3 ended with 22-75 spilled VGPRs in all of them), so each kind has instantiations
+// of its own and the plain kernels - most launches of the step - carry none of it (tests/test_host_logic.py reads .vgpr_spill_count).
+template <int EK = 1>
 __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x16 (&acc)[4][2], char* tl, int m0, int c0, int c1, int grp, int lane) {
     constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
     const int cl = lane & 31, h2 = lane >> 5, g4 = lane >> 4, a16 = lane & 15;
@@ -901,9 +905,12 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
     // (one rounding, exact column sums from two registers) and stores through the plain path.  Opaque to everything else: the tensor
     // is only ever handed from the one call to the other.
     const long blk0 = ((((long)(m0 >> 8) * (p.N >> 8) + (c0 >> 8)) * 8 + grp * 4 + ((c0 & 255) >> 5)) * 8) * 1024 + lane * 16;      // + (i * 2 + j) * 1024
-    if (p.act == 4 && p.aux_blocked) {
+    if (EK == 3 && p.act == 4 && p.aux_blocked) {
         const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux) + blk0;
         u32x4 ax[2][4];                                      // [buffer][j * 2 + half]: 16 rows of the left / right column
+        // (one operand set requested right after the previous one is consumed, or scheduling barriers between the blocks, leave the
+        //  register count where it is - 38 spilled in the persistent instantiation, 21 per-tile: it is the accumulators + the tile-walking
+        //  state + ONE set that do not fit, and two sets keep a block's loads under the previous block's stores)
         auto load_blk = [&](int i, u32x4 (&dst)[4]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const u32x4*>(Ab + (i * 2 + (q >> 1)) * 1024 + (q & 1) * 8);
@@ -931,7 +938,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
             if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
         }
-    } else if (p.act == 3 && Xb && p.aux_blocked) {
+    } else if (EK == 2 && p.act == 3 && Xb && p.aux_blocked) {
         bf16_t* Bb = Xb + blk0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -951,7 +958,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             }
             emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
         }
-    } else if (A4 && p.act == 4) {
+    } else if (EK == 1 && p.act == 4) {
         // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
         // output, and `emit` hands every lane its results as 16-byte row pieces - the very pieces (same row, same eight columns) a 16-byte
         // load of the saved tensor returns.  So the product is formed THERE, on the way out: eight bf16 x bf16 -> fp32 products per piece,
@@ -1122,7 +1129,7 @@ __device__ __forceinline__ void pp_epilogue_f32_direct(const GemmParams& p, cons
 // phase Y reads A half 1 (8 reads), stages B half 0 / A half 0 / B half 1 of the K-tile after next (6 copies: those slots were last read
 // in phase X) and multiplies A half 1 by both B halves.  Every half-tile is requested two phases (one K-tile) before it is read;
 // vmcnt(8) in every phase.  Half as many barrier pairs per MFMA.
-template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1, int BIG = 0, bool A4 = true>
+template <typename TO, bool TA, bool TB, int PP_LEAD = 4, int PRIO = 1, int BIG = 0, int EK = 1>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1312,10 +1319,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
         // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
         const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && p.row_group == 0 && !p.drop_thresh && !p.dbg_skip_epilogue &&
-                            (p.act == 0 || p.act == 1 || p.act == 3 || ((A4 || p.aux_blocked) && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
+                            (p.act == 0 || p.act == 1 || (p.act == 3 && (!p.aux_blocked || EK == 2)) || (((EK == 1 && !p.aux_blocked) || (EK == 3 && p.aux_blocked)) && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
-            pp_epilogue_bf16<A4>(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
+            pp_epilogue_bf16<EK>(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
             if (pf_ok) wait_vm<16>();                                // >= 16 stores were issued after the tail's copies: those have landed
             if (p.dbg_trace && tid == 0) {
                 const unsigned long long tr3 = wall_clock64();
@@ -1365,11 +1372,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1, int BIG = 0, bool A4 = true>
+template <typename TO, bool TA, bool TB, int LEAD = 4, int PRIO = 1, int BIG = 0, int EK = 1>
 int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
-    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO, BIG, A4>;
+    auto kern = gemm_pp_kernel<TO, TA, TB, LEAD, PRIO, BIG, EK>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
@@ -1432,7 +1439,7 @@ __device__ __forceinline__ PP2Item pp2_item(const GemmParams& p, int t, int tile
 // SCHED (where a phase's two global->LDS copies are issued; the load segment of a phase - fragment reads + copies + waits - measured
 // longer than the 8-MFMA segment it is supposed to hide under): 0 = both in the load segment (the per-tile kernel's order), 1 = both
 // inside the wave's own MFMA cluster, 2 = one and one, 3 = both in the load segment but ahead of the fragment reads.
-template <typename TO, bool TA, bool TB, int SCHED = 0, bool A4 = true>
+template <typename TO, bool TA, bool TB, int SCHED = 0, int EK = 1>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1575,7 +1582,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p) {
         if constexpr (sizeof(TO) == 2) {
             const unsigned lp = cpar ^ 1u;
             char* tl = lds + (wave < 7 ? lp * (2 * PP_HALF) + wave * 4608 : PP_BREG + (lp * 2 + 1) * PP_HALF);
-            pp_epilogue_bf16<A4>(p, acc, tl, cur.m0, c0, c1, grp, lane);
+            pp_epilogue_bf16<EK>(p, acc, tl, cur.m0, c0, c1, grp, lane);
         } else {
             pp_epilogue_f32_direct(p, acc, cur.m0, c0, c1, grp, lane);
         }
@@ -1617,12 +1624,12 @@ bool pp2_ok(const GemmParams& p, int splitk) {
     return !p.aux && p.act == 0 && !p.colsum && !p.accumulate;
 }
 
-template <typename TO, bool TA, bool TB, int SCHED = 0, bool A4 = true>
+template <typename TO, bool TA, bool TB, int SCHED = 0, int EK = 1>
 int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
     constexpr int SMEM = 9 * PP_HALF;
     static bool configured = false;
     static int blocks = 0;
-    auto kern = gemm_pp2_kernel<TO, TA, TB, SCHED, A4>;
+    auto kern = gemm_pp2_kernel<TO, TA, TB, SCHED, EK>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return simseg_set_error("simseg_gemm: cannot reserve %d bytes of LDS: %s", SMEM, hipGetErrorString(e));
@@ -1796,6 +1803,18 @@ int dispatch_small(const GemmParams& p, hipStream_t s) {
 
 thread_local int g_gemm_variant = 0;
 
+// the persistent kernel's instantiation for this call's epilogue kind (see pp_epilogue_bf16: each heavy kind has kernels of its own)
+template <typename TO, bool TA, bool TB>
+int launch_pp2_ek(const GemmParams& p, hipStream_t s, int reserve) {
+    if constexpr (sizeof(TO) == 2) {      // (the kinds exist for 16-bit outputs only; the blocked image: fc1 forward = NT, dgrad through fc2 = NN)
+        if (p.act == 4 && !p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 1>(p, s, reserve);
+        if constexpr (!TB) { if (p.act == 3 && p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 2>(p, s, reserve); }
+        if constexpr (TB) { if (p.act == 4 && p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 3>(p, s, reserve); }
+    }
+    if (p.aux_blocked) return simseg_set_error("simseg_gemm: act 5 is a forward (x . W^T) epilogue, act 6 a dgrad (d . W) epilogue, both with 16-bit outputs");
+    return launch_pp2<TO, TA, TB, 0, 0>(p, s, reserve);
+}
+
 template <typename TO, bool TA, bool TB>
 int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) {
     const bool big_ok = aligned && p.K % 64 == 0 && p.M >= 256 && p.N >= 128;
@@ -1871,25 +1890,31 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
             if (act4 < 0) { const char* e = getenv("SIMSEG_GEMM_PP2_ACT4"); act4 = e ? atoi(e) : 0; }
             if ((g_gemm_variant == 18 || g_gemm_variant == 0) && tiles256 >= min_tiles && (p.act != 4 || p.aux_blocked || act4) && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
-                if (p.act == 4 && !p.aux_blocked) return launch_pp2<TO, TA, TB, 0, true>(p, s, reserve);
-                return launch_pp2<TO, TA, TB, 0, false>(p, s, reserve);
+                return launch_pp2_ek<TO, TA, TB>(p, s, reserve);
             }
             if (g_gemm_variant >= 10 && g_gemm_variant <= 13 && pp2_ok<TO>(p, splitk)) {
                 g_gemm_last_variant = 10;
+                if (g_gemm_variant != 10 && p.aux_blocked) return simseg_set_error("simseg_gemm: the schedule experiments (variants 11-13) do not carry the tile-blocked epilogues");
                 switch (g_gemm_variant) {           // 11..13: schedule experiments (see SCHED)
                     case 11: return launch_pp2<TO, TA, TB, 1>(p, s);
                     case 12: return launch_pp2<TO, TA, TB, 2>(p, s);
                     case 13: return launch_pp2<TO, TA, TB, 3>(p, s);
-                    default: return launch_pp2<TO, TA, TB, 0>(p, s);
+                    default: return launch_pp2_ek<TO, TA, TB>(p, s, 0);
                 }
             }
         }
         g_gemm_last_variant = 3;
         // 16-MFMA phases (round 3) unless variant 15 asks for the four-phase schedule (A/B runs)
         if (!four_phase && p.K >= 128) {
-            if (sizeof(TO) == 2 && (p.act != 4 || p.aux_blocked)) return launch_pp<TO, TA, TB, 4, 1, 1, false>(p, splitk, s);
+            if constexpr (sizeof(TO) == 2 && !TA) {
+                if constexpr (!TB) { if (p.act == 3 && p.aux_blocked) return launch_pp<TO, TA, TB, 4, 1, 1, 2>(p, splitk, s); }
+                if constexpr (TB) { if (p.act == 4 && p.aux_blocked) return launch_pp<TO, TA, TB, 4, 1, 1, 3>(p, splitk, s); }
+            }
+            if (p.aux_blocked) return simseg_set_error("simseg_gemm: act 5 is a forward (x . W^T) epilogue, act 6 a dgrad (d . W) epilogue");
+            if (sizeof(TO) == 2 && p.act != 4) return launch_pp<TO, TA, TB, 4, 1, 1, 0>(p, splitk, s);
             return launch_pp<TO, TA, TB, 4, 1, 1>(p, splitk, s);
         }
+        if (p.aux_blocked) return simseg_set_error("simseg_gemm: the four-phase schedule (variant 15) does not carry the tile-blocked epilogues");
         return launch_pp<TO, TA, TB>(p, splitk, s);
     }
     if (v == 2) return launch_large<TO, TA, TB, 64, 2, 256, 256, 2, 4, 2>(p, splitk, s);

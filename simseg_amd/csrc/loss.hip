@@ -222,11 +222,27 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // null) is the bf16 compute copy the next forward's GEMMs read: refreshed here, so no per-step cast kernels.
 struct AdamTensors { float* p; const float* g; float* m; float* v; bf16_t* p16; float lr; float wd; };
 static_assert(sizeof(AdamTensors) == 48, "table rows are six 8-byte words");
+// AMP form (round 4): the loss scale, the overflow flag and the count of steps actually taken live on the DEVICE (amp.scale / amp.found_inf:
+// torch.amp.GradScaler's tensors, handed over through its `optimizer.grad_scale` / `optimizer.found_inf` contract; amp.step_in / step_out:
+// this optimizer's own two-slot counter).  The gradients are unscaled here (g / scale), and a step whose gradients held an inf / nan updates
+// nothing - the decision never travels to the host, so the reference's fp16 iteration (clip_runner.py:226-230, core/hooks/optimizer.py:73-82)
+// runs without the host read torch's scaler.step() makes for an optimizer that cannot skip by itself.  Bias corrections come from the device
+// counter (skipped steps do not count, as in torch's own fused Adam).
+struct AdamAmp { const float* scale; const float* found_inf; const float* step_in; float* step_out; };
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __restrict__ table, const long* __restrict__ sizes,
                                                           const int* __restrict__ chunk_tid, const long* __restrict__ chunk_off,
                                                           int chunk, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                          float grad_scale) {
+                                                          float grad_scale, AdamAmp amp) {
     const int c = blockIdx.x;
+    if (amp.step_in) {
+        const bool skip = amp.found_inf && amp.found_inf[0] != 0.f;
+        const float st = amp.step_in[0] + (skip ? 0.f : 1.f);
+        if (c == 0 && threadIdx.x == 0) amp.step_out[0] = st;      // (the other slot: nobody reads it during this launch)
+        if (skip) return;
+        bc1 = 1.0f - powf(b1, st);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, st));
+        if (amp.scale) grad_scale /= amp.scale[0];
+    }
     const int t = chunk_tid[c];
     const AdamTensors T = table[t];
     const long lo = chunk_off[c];
@@ -272,6 +288,32 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensors* __r
         T.p[i] = pi; T.m[i] = mi; T.v[i] = vi;
         if (T.p16) T.p16[i] = (bf16_t)pi;
     }
+}
+
+// found[0] = 1 if any gradient element of the table's tensors is inf / nan (read-only pass, 16 bytes per lane, one store per block that
+// sees one): the overflow check of torch.amp.GradScaler (`_amp_foreach_non_finite_check_and_unscale_` with inverse scale 1: a read-modify-
+// write pass over every gradient tensor) as ONE launch over the optimizer's own tensor table; the unscaling itself rides on the AdamW kernel.
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const AdamTensors* __restrict__ table, const long* __restrict__ sizes,
+                                                              const int* __restrict__ chunk_tid, const long* __restrict__ chunk_off,
+                                                              int chunk, float* __restrict__ found) {
+    const int c = blockIdx.x;
+    const int t = chunk_tid[c];
+    const float* g = table[t].g;
+    const long lo = chunk_off[c];
+    const long hi = min(sizes[t], lo + chunk);
+    unsigned bad = 0;
+    long i0 = lo;
+    if ((uintptr_t)(g + lo) % 16 == 0) {
+        const long n4 = (hi - lo) / 4;
+        for (long q = threadIdx.x; q < n4; q += 256) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g + lo + 4 * q));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= ((v[e] & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+        }
+        i0 = lo + 4 * n4;
+    }
+    for (long i = i0 + threadIdx.x; i < hi; i += 256) bad |= ((__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) found[0] = 1.0f;
 }
 
 }  // namespace
@@ -360,8 +402,35 @@ extern "C" int simseg_adamw_multi_step(const void* table, const int64_t* sizes, 
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, STREAM, (const AdamTensors*)table, (const long*)sizes,
-                       (const int*)chunk_tid, (const long*)chunk_off, chunk, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+                       (const int*)chunk_tid, (const long*)chunk_off, chunk, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale, AdamAmp{});
     SS_LAUNCH_CHECK("adamw_multi_step");
+    return 0;
+}
+
+extern "C" int simseg_adamw_multi_step_amp(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
+                                           int64_t n_chunks, int chunk, float beta1, float beta2, float eps, float grad_scale,
+                                           const float* loss_scale, const float* found_inf, const float* step_in, float* step_out, void* stream) {
+    SS_HALF_FWD(simseg_adamw_multi_step_amp, table, sizes, chunk_tid, chunk_off, n_chunks, chunk, beta1, beta2, eps, grad_scale, loss_scale,
+                found_inf, step_in, step_out, stream);
+    SS_CHECK(table && sizes && chunk_tid && chunk_off && step_in && step_out && step_in != step_out, "adamw_multi_step_amp: null / aliased pointer");
+    SS_CHECK(chunk > 0, "adamw_multi_step_amp: bad chunk");
+    if (n_chunks <= 0) return 0;
+    AdamAmp amp{loss_scale, found_inf, step_in, step_out};
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, STREAM, (const AdamTensors*)table, (const long*)sizes,
+                       (const int*)chunk_tid, (const long*)chunk_off, chunk, beta1, beta2, eps, 1.0f, 1.0f, grad_scale, amp);
+    SS_LAUNCH_CHECK("adamw_multi_step_amp");
+    return 0;
+}
+
+extern "C" int simseg_grads_nonfinite(const void* table, const int64_t* sizes, const int32_t* chunk_tid, const int64_t* chunk_off,
+                                      int64_t n_chunks, int chunk, float* found_inf, void* stream) {
+    SS_HALF_FWD(simseg_grads_nonfinite, table, sizes, chunk_tid, chunk_off, n_chunks, chunk, found_inf, stream);
+    SS_CHECK(table && sizes && chunk_tid && chunk_off && found_inf, "grads_nonfinite: null pointer");
+    SS_CHECK(chunk > 0, "grads_nonfinite: bad chunk");
+    if (n_chunks <= 0) return 0;
+    hipLaunchKernelGGL(grads_nonfinite_kernel, dim3((unsigned)n_chunks), dim3(256), 0, STREAM, (const AdamTensors*)table, (const long*)sizes,
+                       (const int*)chunk_tid, (const long*)chunk_off, chunk, found_inf);
+    SS_LAUNCH_CHECK("grads_nonfinite");
     return 0;
 }
 

@@ -22,13 +22,21 @@ RING = 4
 
 
 class AdamW(torch.optim.Optimizer):
+    # torch.amp.GradScaler's contract for optimizers that handle the loss scale themselves (grad_scaler.py: `_step_supports_amp_scaling`):
+    # scaler.step(optimizer) then sets optimizer.grad_scale / optimizer.found_inf (device tensors) and calls step() WITHOUT reading the
+    # overflow flag on the host; the kernel unscales the gradients and skips the update on the device (simseg_adamw_multi_step_amp).
+    _step_supports_amp_scaling = True
+
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3, half_dtype=torch.bfloat16):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if half_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("half_dtype: torch.bfloat16 (headline mode) or torch.float16 (the reference's AMP type)")
         self.half_dtype = half_dtype      # type of the 16-bit compute copies the kernel writes (what the towers' GEMMs read next step)
-        self._step = 0
+        self._step = 0                    # step() calls without a GradScaler (every one of them updates)
+        self._step_dev = None             # AMP: float32 [2] on the device, the count of steps actually TAKEN (skipped ones do not count)
+        self._amp_calls = 0               #      which slot is current
         self._plans = {}
+        self._prepared = None
 
     # ---- launch plan: everything about a set of tensors that does not change from step to step ------------------------------
     def _plan(self, key, params):
@@ -73,15 +81,19 @@ class AdamW(torch.optim.Optimizer):
         self._plans[key] = plan
         return plan
 
-    @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
-        self._step += 1
+    def _prepare(self):
+        """Per-step tables of every bucket (gradient pointers, learning rates) uploaded; reused by the call that follows immediately
+        (found_inf_check() then step() inside one scaler.step)."""
+        grads_now = tuple(id(p.grad) for g in self.param_groups for p in g["params"])
+        if self._prepared is not None and self._prepared[0] == grads_now:
+            return self._prepared[1]
         buckets = {}
         for group in self.param_groups:
             key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
             for p in group["params"]:
                 if p.grad is not None:
                     buckets.setdefault(key, []).append((p, float(group["lr"]), float(group["weight_decay"])))
+        ready = []
         for key, items in buckets.items():
             params = [it[0] for it in items]
             if any(not p.is_contiguous() or p.dtype != torch.float32 for p in params):
@@ -106,21 +118,71 @@ class AdamW(torch.optim.Optimizer):
             ev = torch.cuda.Event()
             ev.record()
             plan["events"][slot] = ev
+            plan["keepalive"] = grads        # the kernels read them asynchronously
+            ready.append((key, plan, params))
+        self._prepared = (grads_now, ready)
+        return ready
+
+    @torch.no_grad()
+    def found_inf_check(self, found_inf):
+        """found_inf (float32 scalar tensor on the device) = 1 if any gradient holds an inf / nan: GradScaler's overflow check as one
+        read-only launch per bucket over this optimizer's tensor table (simseg_amd.optim.GradScaler calls it instead of torch's
+        read-modify-write pass over every gradient tensor)."""
+        for key, plan, params in self._prepare():
+            call("simseg_grads_nonfinite", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"], CHUNK,
+                 ptr(found_inf), stream())
+        return found_inf
+
+    def steps_taken(self):
+        """Updates actually applied (a host read of the device counter when a GradScaler drives this optimizer: skipped steps do not count)."""
+        if self._step_dev is not None:
+            return int(round(float(self._step_dev[self._amp_calls & 1])))
+        return self._step
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        # torch.amp.GradScaler.step() sets these two attributes around the call (and deletes them afterwards)
+        loss_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        amp = loss_scale is not None or found_inf is not None
+        ready = self._prepare()
+        self._prepared = None
+        if amp:
+            if self._step_dev is None:       # the device counter takes over from the host one
+                dev = ready[0][1]["table"].device if ready else torch.device("cuda")
+                self._step_dev = torch.full((2,), float(self._step), device=dev, dtype=torch.float32)
+                self._amp_calls = 0
+            for t in (loss_scale, found_inf):
+                if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+                    raise TypeError("grad_scale / found_inf: float32 tensors on the device (torch.amp.GradScaler's)")
+        else:
+            if self._step_dev is not None:   # back from a GradScaler-driven phase: one host read of how many of its steps were taken
+                self._step = self.steps_taken()
+                self._step_dev = None
+            self._step += 1
+        for key, plan, params in ready:
             note_half(self.half_dtype)        # (the 16-bit copies are addressed through the table: tell the binding which flavour they are)
-            call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
-                 CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
-            plan["keepalive"] = grads        # the kernel reads them asynchronously
+            if amp:
+                cur = self._amp_calls & 1
+                call("simseg_adamw_multi_step_amp", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
+                     CHUNK, key[0], key[1], key[2], float(grad_scale), ptr(loss_scale), ptr(found_inf), ptr(self._step_dev[cur:cur + 1]),
+                     ptr(self._step_dev[1 - cur:2 - cur]), stream())
+            else:
+                call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
+                     CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
             for p in params:                 # same stream as the next forward: the copies are current when it runs
                 register_w16(p, self.state[p]["p16"])
                 drop_split_copy(p)           # the exact-mode split-bf16 copy of the OLD value (raw-pointer update: _version did not move)
+        if amp:
+            self._amp_calls += 1             # (several buckets: every launch of this call read the same slot and wrote the other)
 
     # ---- checkpoints in torch.optim.AdamW's layout ---------------------------------------------------------------------
     def state_dict(self):
         sd = super().state_dict()
+        steps = self.steps_taken()
         out = {}
         for idx, st in sd["state"].items():
             if "m" in st:
-                out[idx] = {"step": torch.tensor(float(self._step)), "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
+                out[idx] = {"step": torch.tensor(float(steps)), "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
         sd["state"] = out
         for g in sd["param_groups"]:            # keys torch.optim.AdamW.load_state_dict expects to find
             g.setdefault("amsgrad", False)
@@ -144,3 +206,23 @@ class AdamW(torch.optim.Optimizer):
             st["m"], st["v"] = st["m"].float().contiguous(), st["v"].float().contiguous()
             st.pop("p16", None)
         self._step = max(steps) if steps else 0
+        self._step_dev, self._amp_calls, self._prepared = None, 0, None
+
+
+class GradScaler(torch.amp.GradScaler):
+    """torch.amp.GradScaler (same state, same state_dict, same scale / step / update calls as the reference makes: clip_runner.py:226-230,
+    core/hooks/optimizer.py:73-82) whose overflow check of a simseg_amd AdamW is that optimizer's one read-only kernel instead of torch's
+    read-modify-write pass over ~400 gradient tensors.  With either scaler the step has no host read: the skip decision stays on the device
+    (AdamW._step_supports_amp_scaling)."""
+
+    def __init__(self, device="cuda", **kw):
+        super().__init__(device, **kw)
+
+    def _check_inf_per_device(self, optimizer):
+        if not isinstance(optimizer, AdamW):
+            return super()._check_inf_per_device(optimizer)
+        _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
+        found_inf = torch.zeros((), dtype=torch.float32, device=_scale.device)
+        optimizer.found_inf_check(found_inf)
+        self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = {_scale.device: found_inf}
+        return self._per_optimizer_states[id(optimizer)]["found_inf_per_device"]

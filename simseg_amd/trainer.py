@@ -16,7 +16,7 @@ import time
 
 import torch
 
-from .optim import AdamW
+from .optim import AdamW, GradScaler
 
 
 # ---- stateless learning-rate multipliers (functions of the global step only) -----------------------------------------
@@ -68,7 +68,8 @@ class Trainer:
         if amp not in ("bf16", "bfloat16", "fp16", "float16", "half"):
             raise ValueError(f"amp_dtype {amp!r}: bf16 or fp16")
         self.amp_dtype = torch.float16 if amp in ("fp16", "float16", "half") else torch.bfloat16
-        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(cfg.dist.fp16) and self.amp_dtype == torch.float16)
+        # (torch.amp.GradScaler with this package's overflow check: one read-only kernel; no host read in scaler.step either way)
+        self.scaler = GradScaler("cuda", enabled=bool(cfg.dist.fp16) and self.amp_dtype == torch.float16)
         groups = param_groups(model, cfg)
         p = dict(cfg.optim.param)
         if cfg.optim.name.endswith("AdamW"):

@@ -890,6 +890,52 @@ def test_adamw_multi_tensor_optimizer():
         _close(a.detach(), b.detach(), 1e-5, "multi-tensor adamw")
 
 
+def test_adamw_under_a_gradscaler_unscales_and_skips_on_the_device():
+    """torch.amp.GradScaler's contract for optimizers that handle the scale themselves (`_step_supports_amp_scaling`): scaler.step() hands
+    over the loss scale and the overflow flag as DEVICE tensors; the kernel unscales the gradients, skips the whole update when the flag is
+    set, and counts on the device the steps it really took (bias corrections: skipped steps do not count, as in torch's fused Adam).  The
+    trajectory equals torch.optim.AdamW + torch's scaler on the same scaled gradients, for torch's scaler and for this package's (one
+    read-only kernel as the overflow check); no call reads the device."""
+    from simseg_amd.optim import AdamW, GradScaler
+    shapes = [(768, 768), (3072,), (), (70000, 3)]
+    for Scaler in (torch.amp.GradScaler, GradScaler):
+        ours = [torch.nn.Parameter(_rand(*s, seed=i) if s else torch.tensor(0.02, device="cuda")) for i, s in enumerate(shapes)]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+        o1 = AdamW(ours, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-2)
+        o2 = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-2)
+        s1, s2 = Scaler("cuda", init_scale=1024.0, growth_interval=3), torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=3)
+        for sc in (s1, s2):
+            sc.scale(torch.zeros((), device="cuda"))          # (lazy init of the scale tensor)
+        for step in range(7):
+            scale = s2.get_scale()
+            for i, (a, b) in enumerate(zip(ours, ref)):
+                g = (_rand(*shapes[i], seed=100 * step + i) if shapes[i] else torch.tensor(0.3 * (step + 1), device="cuda")) * scale
+                if step in (1, 4) and i == (step % len(shapes)):
+                    g = g.clone()
+                    g.view(-1)[g.numel() // 2] = float("inf") if step == 1 else float("nan")       # an overflowing step
+                a.grad, b.grad = g.clone(), g.clone()
+            torch.cuda.synchronize()
+            if step > 0:                                      # (the first call builds the launch plan: host -> device copies of its index tables)
+                torch.cuda.set_sync_debug_mode("error")
+            try:
+                s1.step(o1)
+                s1.update()
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            s2.step(o2); s2.update()
+            assert s1.get_scale() == s2.get_scale(), (step, s1.get_scale(), s2.get_scale())
+        assert o1.steps_taken() == 5                              # seven calls, two skipped
+        for a, b in zip(ours, ref):
+            _close(a.detach(), b.detach(), 1e-5, f"adamw under {Scaler.__module__}.GradScaler")
+        # back to plain steps: the host counter picks up where the device one stood
+        for a, b in zip(ours, ref):
+            a.grad, b.grad = torch.ones_like(a), torch.ones_like(b)
+        o1.step(); o2.step()
+        assert o1.steps_taken() == 6
+        for a, b in zip(ours, ref):
+            _close(a.detach(), b.detach(), 1e-5, "plain step after the scaled ones")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,C,K", [(324, 21, 512), (1024, 171, 512), (777, 60, 512), (130, 81, 384), (4096, 256, 512), (64, 1, 128)])
 def test_patch_text_sim_fused(ops, dtype, M, C, K):
