@@ -273,12 +273,39 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     # fused dilate+erode, and read again for the argmax / IoU pass; the label map is read once per window.  (All five slots are
     # read by the argmax pass as the reference's temp_pred[...] stack would be: counted for visited ones only.)
     post_bytes = img * img * (4 * visited + windows)
-    return {"post_ms_per_step": round(post_ms, 3), "post_visited_candidates_per_window": round(visited / windows, 2),
-            "post_GBps": round(post_bytes / post_ms / 1e6, 1),
-            "post_frac_of_hbm_peak": round(post_bytes / post_ms / 1e6 / 8000.0, 4), "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
-            "classes": classes, "windows_per_batch": windows, "batches_in_flight": 2, "dense_crf": bool(crf),
-            "tflops_per_gpu": round(wps / world * fl / 1e12, 1),
-            "frac_of_peak": round(wps / world * fl / (PEAK_BF16 if dtype == "bf16" else PEAK_F32), 4)}
+    out = {"post_ms_per_step": round(post_ms, 3), "post_visited_candidates_per_window": round(visited / windows, 2),
+           "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
+           "classes": classes, "windows_per_batch": windows, "batches_in_flight": 2, "dense_crf": bool(crf),
+           "tflops_per_gpu": round(wps / world * fl / 1e12, 1)}
+    if crf:
+        # The DenseCRF stage is hash-table / scattered-gather work; its traffic is not derivable from tensor sizes.  What it moves per
+        # window comes from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_crf.sh (profiles/r4_crf_traffic.json, when
+        # that file was measured on this tree's crf.hip) - never from dividing the similarity-map bytes by the stage time.
+        out["post_stage"] = "candidate maps -> DenseCRF (permutohedral mean field) -> 7x7 closing -> resize + argmax + histograms"
+        try:
+            with open(os.path.join(REPO, "profiles", "r4_crf_traffic.json")) as f:
+                tj = json.load(f)
+            ent = tj.get(f"{img}")
+            if ent and tj.get("crf_hip_blob") == git_blob_sha1(os.path.join(REPO, "simseg_amd", "csrc", "crf.hip")):
+                mb = ent["hbm_mb_per_window"]
+                out["post_hbm_MB_per_window_pmc"] = mb
+                out["post_GBps_pmc"] = round(mb * windows / post_ms, 1)               # MB per ms = GB/s
+                out["post_frac_of_hbm_peak_pmc"] = round(mb * windows / post_ms / 8000.0, 4)
+        except (OSError, ValueError, KeyError):
+            pass
+    else:
+        out["post_GBps"] = round(post_bytes / post_ms / 1e6, 1)
+        out["post_frac_of_hbm_peak"] = round(post_bytes / post_ms / 1e6 / 8000.0, 4)
+    if dtype == "bf16":
+        out["frac_of_peak"] = round(wps / world * fl / PEAK_BF16, 4)
+    else:
+        # Exact mode runs on the bf16 matrix pipe since round 3 (six bf16 piece products per fp32 product: simseg_split_bf16x3,
+        # attn_fwd_x3), so the hardware fraction is 6 x the algorithmic fp32 FLOPs against the bf16 peak; the fraction of the fp32 MFMA
+        # peak is what an fp32-MFMA implementation would have to reach for the same throughput (it can exceed 1 for that reason).
+        out["frac_of_peak"] = round(6.0 * wps / world * fl / PEAK_BF16, 4)
+        out["frac_of_peak_counts"] = "6 bf16 piece products per algorithmic fp32 product, against the dense bf16 MFMA peak (the pipe the kernels use)"
+        out["fp32_equivalent_frac_of_fp32_mfma_peak"] = round(wps / world * fl / PEAK_F32, 4)
+    return out
 
 
 def seg_latency_bench(dev, dtype, img, classes, tag, dim, reps=50):
@@ -341,7 +368,10 @@ def retrieval_bench(dev, m=5000, n=25000, d=512, reps=5):
     dt = (time.perf_counter() - t0) / reps
     # "similarities" counts both directions' M x N scores as the reference's two calls produce them (2 M N), computed here once
     return {"shape": f"{m}x{n}x{d}, both directions", "ms_per_eval": round(dt * 1e3, 3), "similarities_per_s": round(2.0 * m * n / dt, 1),
-            "gemm_tflops_fp32": round(2.0 * m * n * d / dt / 1e12, 1), "gemm_launches_per_eval": 1,
+            "gemm_tflops_fp32_equivalent": round(2.0 * m * n * d / dt / 1e12, 1),
+            "gemm_note": "the whole evaluation's time (GEMM + two rank passes) divided into the algorithmic fp32 FLOPs; the matrix itself is the "
+                         "split-bf16 form: 6 bf16 piece products per fp32 product on the bf16 MFMA pipe",
+            "gemm_launches_per_eval": 1,
             "i2t_R@1": round(a["R@1"], 4), "t2i_R@1": round(b["R@1"], 4)}
 
 
@@ -410,6 +440,47 @@ def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250
     del model
     return {"shape": f"{n_img} images @{img}^2 + {n_img * cap_per_img} captions L={L}, bf16 towers", "seconds": round(dt, 3),
             "images_per_s": round(n_img / dt, 1), "captions_per_s": round(n_img * cap_per_img / dt, 1)}
+
+
+def attention_roofline(dev, B, img, L, H=12, reps=10):
+    """The bf16 attention kernels of the step, each timed alone (events, `reps` launches) on the step's own shapes: the image tower's
+    (B, T = 1 + (img/16)^2) and the text tower's (B, L) with dropout and a ragged key-padding mask.  FLOPs = 4 T^2 64 per head forward,
+    2.5x that backward (five tile products against two); bytes = qkv read + ctx written (forward), + dO, O read and dqkv written (backward).
+    Both fractions are given: at these lengths the kernels are bound by HBM traffic and softmax VALU work, not by the matrix pipe."""
+    from simseg_amd import ops
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    for name, T, drop in (("attention_image_tower", 1 + (img // 16) ** 2, 0.0), ("attention_text_tower", L, 0.1)):
+        qkv = torch.randn(B, T, 3 * H * 64, device=dev, generator=g).bfloat16()
+        mask, lens2 = None, float(T) * T * B
+        if drop:
+            lens = torch.randint(8, T + 1, (B,), device=dev, generator=g)
+            mask = (torch.arange(T, device=dev)[None] < lens[:, None]).long()
+            lens2 = float((lens.double() ** 2).sum())
+        out_, lse = ops.attention_fwd(qkv, H, mask, scale=0.125, save_lse=True, drop_seed=3, drop_p=drop)
+        do = torch.randn_like(out_)
+        tf = timed(lambda: ops.attention_fwd(qkv, H, mask, scale=0.125, save_lse=True, drop_seed=3, drop_p=drop))
+        tb = timed(lambda: ops.attention_bwd(qkv, out_, do, lse, H, mask, scale=0.125, drop_seed=3, drop_p=drop))
+        fl = 4.0 * 64 * H * (lens2 if mask is not None else float(T) * T * B)
+        by = 2.0 * B * T * H * 64 * 4                     # q, k, v read + ctx written, 2 bytes each
+        for tag, sec, f, b in (("fwd", tf, fl, by), ("bwd", tb, 2.5 * fl, by * 2.0)):
+            out[f"{name}_{tag}"] = {"shape": f"B={B} T={T} H={H}" + (" ragged mask, dropout 0.1" if drop else ""), "ms": round(sec * 1e3, 4),
+                                    "tflops": round(f / sec / 1e12, 1), "frac": round(f / sec / PEAK_BF16, 4),
+                                    "GBps": round(b / sec / 1e9, 1), "frac_of_hbm_peak": round(b / sec / 8e12, 4)}
+        del qkv, out_, lse, do
+    return out
 
 
 class ClockSampler:
@@ -551,11 +622,18 @@ def main():
     model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
     net = model
     sync = None
-    dp = os.environ.get("SIMSEG_BENCH_DP", "ddp")      # "ddp": torch DDP (bucketed all-reduce overlapped with backward, towers on one
-    if world > 1:                                       # stream); "flat": simseg_amd.parallel.GradSync (one all-reduce, two-stream towers)
-        if dp in ("flat", "bucket"):       # this package's exchange: keeps the two-stream towers; "bucket" overlaps it with the backward
+    # Gradient exchange for N > 1 (SIMSEG_BENCH_DP): "bucket" (DEFAULT since round 4) = simseg_amd.parallel.GradSync - bucketed RCCL
+    # all-reduces enqueued behind the backward of BOTH tower streams, i.e. the same two-stream tower schedule as the N = 1 line, so that the
+    # 1 -> N ratio measures communication and not a schedule change (tested equal to torch DDP's averaged gradients on 2 ranks);
+    # "flat" = the same with one all-reduce after the backward; "ddp" = torch DDP, whose bucket hooks synchronise with ONE stream: the
+    # towers then run on one stream (+5-6 ms per step at N = 1).
+    dp = os.environ.get("SIMSEG_BENCH_DP", "bucket")
+    # SIMSEG_BENCH_FORCE_SYNC=1: run the N > 1 exchange machinery (flat gradient buffer, per-parameter hooks, events, communication stream;
+    # collectives are skipped at world size 1) on ONE rank - what the N > 1 schedule costs before any byte travels
+    if world > 1 or os.environ.get("SIMSEG_BENCH_FORCE_SYNC", "0") == "1":
+        if dp in ("flat", "bucket"):
             from simseg_amd.parallel import GradSync
-            sync = GradSync(model.parameters(), overlap=(dp == "bucket"))
+            sync = GradSync(model.parameters(), overlap=(dp == "bucket"), average="defer")      # (the mean over ranks is applied by the AdamW kernel)
             os.environ.setdefault("SIMSEG_AMD_TWO_STREAMS", "1")
         else:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
@@ -584,7 +662,7 @@ def main():
         loss_dict["nce_loss"].backward()
         if sync is not None:
             sync()
-        opt.step()
+        opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0)
         return loss_dict["nce_loss"]
 
     bdf = None
@@ -694,6 +772,7 @@ def main():
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
     ops.PROFILE = None
+    attn_roofline = attention_roofline(dev, B, args.img, L) if rank == 0 else {}
     del net, model, opt, batches
     torch.cuda.empty_cache()
     seg = None
@@ -760,6 +839,15 @@ def main():
         kdesc = {"_P": "gemm_pp_kernel (256x256 tile, two wave groups in ping-pong, direct-to-LDS half-tile ring)",
                  "_Q": "gemm_pp2_kernel (persistent 256x256 ping-pong: one workgroup per CU walks its XCD's tiles, operand copies and the epilogue's stores run across tile boundaries)",
                  "_L": "gemm_large_kernel (256x256 tile, direct-to-LDS ring)"}.get(dom[-2:], "gemm_kernel (128x128 tile, 32x32x16 bf16 MFMA)")
+        # every GEMM class of the instrumented step (kind = operand layout _ output type _ kernel: P per-tile ping-pong, Q persistent
+        # ping-pong, S small-problem, none = 128x128), the aggregate, and the attention kernels timed alone on the same shapes
+        per_class = {k: {"launches": v[0], "ms": round(1e3 * v[2], 3), "tflops": round(v[1] / v[2] / 1e12, 1),
+                         "frac": round(v[1] / v[2] / (PEAK_F32 if k.startswith("f32") else PEAK_BF16), 4)} for k, v in sorted(agg.items())}
+        gfl = sum(v[1] for k, v in agg.items() if not k.startswith("f32"))
+        gsec = sum(v[2] for k, v in agg.items() if not k.startswith("f32"))
+        per_class["all_bf16_gemms"] = {"launches": sum(v[0] for k, v in agg.items() if not k.startswith("f32")), "ms": round(1e3 * gsec, 3),
+                                       "tflops": round(gfl / gsec / 1e12, 1), "frac": round(gfl / gsec / PEAK_BF16, 4)}
+        per_class.update(attn_roofline)
         out = {
             "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",
             "value_is": "training image-text pairs/s over all ranks; the zero-shot-seg eval rate is reported in seg_eval", "n_gpus": world,
@@ -772,14 +860,18 @@ def main():
                        "process_group": pg_info, "batches_rotated": NB,
                        "caption_lengths": ("host-side token counts travel with the batch (no host read in the step)" if HOST_LENGTHS
                                            else "derived from the device mask (one host read per step)"),
-                       "gradient_sync": ("none" if world == 1 else (f"simseg_amd.parallel.GradSync ({dp})" if sync is not None else "torch DDP")),
+                       "gradient_sync": ((f"simseg_amd.parallel.GradSync ({dp})" + (" [forced on one rank: no collective]" if world == 1 else "")) if sync is not None
+                                         else ("none" if world == 1 else "torch DDP")),
                        "tower_streams": 2 if two_streams else 1,
+                       "persistent_gemm_reserved_cus": int(os.environ.get("SIMSEG_GEMM_PP2_RESERVE", "0")),
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",
                        "captions": "ragged, lengths U{8..L}" + ("; the padded token rows of the text tower are not computed (same loss and "
                                    "gradients as computing them: SIMSEG_AMD_PACKED_TEXT=0)" if os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0" else "; padded token rows computed")},
             "roofline": {"bound": "mfma", "kernel": f"{kdesc} <{dom}>",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_is": "the GEMM class with the largest summed time; every class, the aggregate and the attention kernels are in per_class",
+                         "per_class": per_class,
                          "launches_per_step": cnt, "avg_launch_ms": round(1e3 * sec / cnt, 4),
                          "flops_per_launch_avg": fl / cnt,
                          "measured": "one instrumented step with both towers on one stream (each launch alone on the GPU); the timed "

@@ -174,6 +174,18 @@ int simseg_scale_rows(const float* x, const float* s, float* y, int64_t rows, in
 /* y[i] = alpha * scalar[0] * x[i] with the scalar read on the device (upstream loss gradient, no host sync). */
 int simseg_scale_by_scalar(const float* x, const float* scalar, float* y, int64_t n, float alpha, void* stream);
 
+/* Both directions of the CLIP loss (simseg/models/pipelines/clip.py:129-140: 0.5 * (NCE(image, text) + NCE(text, image)), each as
+ * simseg_nce_rows without an ignore mask) in two launches: sims2 = the two [N1, N2] similarity blocks stacked (image -> text first), overwritten
+ * by their gradients w.r.t. the similarities when write_grad; row_scratch: 6 * N1 floats; out4 = {loss, i2t top-1 acc, t2i top-1 acc,
+ * dLoss/dTemperature}. */
+int simseg_nce_pair(float* sims2, const float* temperature, float* row_scratch, float* out4, int64_t N1, int64_t N2, int64_t target0,
+                    float smoothing, int write_grad, void* stream);
+/* n <= 6 fp32 transposes in ONE launch (out[k][c, r] = in[k][r, c], in[k] [rows[k], cols[k]] contiguous); jobs with scale[k] != 0 are
+ * multiplied by alpha * scalar[0] - in the transposed copy and IN PLACE; y0[0] = scalar[0] * x0[0] when y0 is given.  The loss head's
+ * backward (mml_loss.py:73 differentiated) needs dS, dS^T and the transposed embeddings as row . row GEMM operands, all times the upstream
+ * gradient: one launch instead of the round-3 head's four transposes and three scale passes per direction. */
+int simseg_transpose_multi(const void* const* in, void* const* out, const int64_t* rows, const int64_t* cols, const int32_t* scale, int64_t n,
+                           const float* scalar, float alpha, const float* x0, float* y0, void* stream);
 /* Retrieval: rank[i] = #{j : sim_ij > max_{j': gid match} sim_ij'}, has_match[i] = any gid match.  Equals the
  * argsort/gather/first-match rank of simseg/tasks/clip/hooks/utils.py:36-42,64-66 on tie-free scores. */
 int simseg_retrieval_rank(const float* sim, const int64_t* left_gid, const int64_t* right_gid, int32_t* has_match, int32_t* rank,

@@ -34,6 +34,13 @@ def init_device(cfg):
         backend = os.environ.get("SIMSEG_DIST_BACKEND") or ("nccl" if has_gpu else "gloo")
         dist.init_process_group(backend=backend, init_method="env://")
     ENV.rank, ENV.size = dist.get_rank(), dist.get_world_size()
+    if ENV.size > 1:
+        # The persistent 256x256 GEMM launches one workgroup per CU that owns it for the whole launch (512 threads x 256 VGPRs, 144 KiB of
+        # LDS: nothing co-resides).  With collectives in flight - RCCL's all-reduce / all-gather kernels are a few dozen workgroups that need
+        # CUs of their own - the launch leaves 16 of the 256 CUs free (read once, at the library's first GEMM; SIMSEG_GEMM_PP2_RESERVE
+        # overrides).  Measured on one GPU: reserves of 0 / 8 / 32 CUs are within 0.4 ms of an 88 ms step.  Not measurable here with RCCL
+        # itself (one GPU per box; RCCL refuses two ranks per device).
+        os.environ.setdefault("SIMSEG_GEMM_PP2_RESERVE", "16")
     ENV.device = torch.device("cuda", ENV.local_rank) if has_gpu else torch.device("cpu")
     for name in ("batch_size", "batch_size_val"):
         bs = cfg.data.get(name)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from simseg.utils import ENV, GatherLayer, logger
 from simseg.utils.dist import generate_local_groups
-from simseg_amd.heads import NCEFn, all_gather_rows
+from simseg_amd.heads import ClipLossFn, NCEFn, all_gather_rows
 
 from .builder import LOSS
 
@@ -45,6 +45,14 @@ class NCE(nn.Module):
         if self.gather_backward and t.requires_grad:
             return GatherLayer.apply(t, self.group, self.rank)
         return all_gather_rows(t, self.group)
+
+    def both(self, image_embeddings, text_embeddings):
+        """0.5 * (self(image, text)[0] + self(text, image)[0]) and the two top-1 accuracies - what CLIPModel.forward_loss computes with
+        two calls of this module (pipelines/clip.py:129-140) - as ONE autograd node with the embedding exchange inside
+        (simseg_amd.heads.ClipLossFn: same kernels, a third of the launches).  global_reduce losses without an ignore mask only."""
+        if not self.global_reduce:
+            raise NotImplementedError("NCE.both: the fused head is the global_reduce form")
+        return ClipLossFn.apply(image_embeddings, text_embeddings, self.temperature, self.group, self.rank, self.smoothing, self.gather_backward)
 
     def forward(self, feat1, feat2, label=None, ignore_mask=None):
         if self.global_reduce:

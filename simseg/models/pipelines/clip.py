@@ -89,7 +89,11 @@ class CLIPModel(nn.Module):
             prefetch_gather(emb, self.loss.group)
 
     def forward_loss(self, image_embeddings, text_embeddings, ignore_mask=None):
-        if self.global_reduce:
+        if (self.global_reduce and ignore_mask is None and hasattr(self.loss, "both") and image_embeddings.is_cuda
+                and os.environ.get("SIMSEG_AMD_FUSED_LOSS", "1") != "0"):
+            # both directions as one node (same arithmetic and kernels as the two calls below: tests/test_gpu_model.py)
+            loss, i2t_acc, t2i_acc = self.loss.both(image_embeddings, text_embeddings)
+        elif self.global_reduce:
             i2t_loss, i2t_acc = self.loss(image_embeddings, text_embeddings, ignore_mask=ignore_mask)
             t2i_loss, t2i_acc = self.loss(text_embeddings, image_embeddings, ignore_mask=ignore_mask)
             loss = 0.5 * (i2t_loss + t2i_loss)

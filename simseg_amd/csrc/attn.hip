@@ -102,14 +102,18 @@ __device__ __forceinline__ void softmax_tile(f32x16 (&s)[2], const float* kbias,
 // `o` holds the UNNORMALISED output accumulators; on return s holds P (to be multiplied into o by the caller).
 constexpr float RESCALE_THR = 6.0f;
 
+// `two` (wave-uniform; EDGE tiles only): false = the tile's second 32-key block is all padding - its scores were not formed, its
+// probabilities are exactly 0 and nobody reads them, so its share of the arithmetic (half of an edge tile's ~150 VALU instructions: at
+// T = 197 the last tile holds 5 keys, at T = 1025 one) is skipped.
 template <bool BIAS, bool EDGE>
 __device__ __forceinline__ void softmax_tile_lean(f32x16 (&s)[2], const float* kbias, int h2, float c, float& m, float& lsum,
-                                                  f32x16 (&o)[2], int klim) {
+                                                  f32x16 (&o)[2], int klim, bool two = true) {
     float mx[4] = {NEG, NEG, NEG, NEG};
     constexpr bool scaled = BIAS || EDGE;          // s is rewritten as the scaled, biased / masked score
     if (scaled) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (EDGE && kb == 1 && !two) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
@@ -119,6 +123,7 @@ __device__ __forceinline__ void softmax_tile_lean(f32x16 (&s)[2], const float* k
                 s[kb][r] = x;
                 mx[r & 3] = fmaxf(mx[r & 3], x);
             }
+        }
     } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -141,13 +146,15 @@ __device__ __forceinline__ void softmax_tile_lean(f32x16 (&s)[2], const float* k
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
     const float nm = -m;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb) {
+        if (EDGE && kb == 1 && !two) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float pr = __builtin_amdgcn_exp2f(scaled ? s[kb][r] + nm : fmaf(s[kb][r], c, nm));
             s[kb][r] = pr;
             ps[r & 3] += pr;
         }
+    }
     lsum += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 }
 
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[1] += t1 - dt0; dt0 = t1; }
         if (MASK) softmax_tile_lean<true, false>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, o, KT);
-        else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0);
+        else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0, two);
         if (DBG) { asm volatile("" ::"v"(s[0][0]), "v"(o[1][15])); unsigned long long t1 = __builtin_readcyclecounter(); dbg[2] += t1 - dt0; dt0 = t1; }
         if (DROP) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
 #pragma unroll
@@ -1063,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             __builtin_amdgcn_sched_barrier(0);
             if (MASK) softmax_tile_lean<true, false>(s, kb_all + kv0, h2, p.scale_log2e, m, lsum, o, KT);
-            else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0);
+            else softmax_tile_lean<false, EDGE>(s, nullptr, h2, p.scale_log2e, m, lsum, o, T - kv0, two);
             if (DROP) {      // HF attention_probs dropout: applied to P after the normaliser is fixed
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)

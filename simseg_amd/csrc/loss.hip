@@ -30,13 +30,15 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(float* __restrict__ sims,
                                                        const float* __restrict__ ignore, float* __restrict__ row_loss,
                                                        float* __restrict__ row_correct, float* __restrict__ row_tdot,
                                                        int N1, int N2, int target0, float smoothing, int write_grad) {
+    // (the pair form - simseg_nce_pair - launches 2 N1 blocks over two stacked [N1, N2] matrices: row i of matrix i / N1)
     __shared__ float sh[8];
     __shared__ int shi[8];
     const int i = blockIdx.x, tid = threadIdx.x;
     float* row = sims + (long)i * N2;
     const float temp = fminf(fmaxf(temperature[0], 0.001f), 0.5f);
     const float inv_t = 1.0f / temp;
-    const int tgt = target0 + i;
+    const int il = i % N1;
+    const int tgt = target0 + il;
     float mx = -INFINITY;
     int arg = 0x7fffffff;
     for (int j = tid; j < N2; j += 256) {
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(float* __restrict__ sims,
     const float zt = row[tgt] * inv_t;
     const float nll = lse - zt;
     const float smooth = lse - sz / N2;                 // -mean_j logp_ij
-    const float w = ignore ? 1.0f - ignore[i] : 1.0f;
+    const float w = ignore ? 1.0f - ignore[il] : 1.0f;
     const float loss = (1.0f - smoothing) * nll + smoothing * smooth;
     __syncthreads();
     float tdot = 0.f;
@@ -110,6 +112,57 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
         // z = s / temp  ->  dL/dtemp = -(1/temp) * sum_ij dz_ij * s_ij / temp ... with tdot = sum dz*s:  -tdot / temp^2
         out[2] = (T >= 0.001f && T <= 0.5f) ? -t / (temp * temp) : 0.f;
     }
+}
+
+// Both directions of the CLIP loss at once (pipelines/clip.py:129-140: 0.5 (i2t + t2i)): rows [0, N1) are the image -> text matrix, rows
+// [N1, 2 N1) the text -> image one.  out = {loss, i2t acc, t2i acc, dLoss/dTemperature}.
+__global__ __launch_bounds__(256) void nce_finalize_pair_kernel(const float* __restrict__ row_loss, const float* __restrict__ row_correct,
+                                                                const float* __restrict__ row_tdot, const float* __restrict__ temperature,
+                                                                float* __restrict__ out, int N1) {
+    __shared__ float sh[8];
+    float l = 0.f, c0 = 0.f, c1 = 0.f, t = 0.f;
+    for (int i = threadIdx.x; i < 2 * N1; i += 256) {
+        l += row_loss[i];
+        t += row_tdot[i];
+        if (i < N1) c0 += row_correct[i]; else c1 += row_correct[i];
+    }
+    l = block_reduce_sum(l, sh); c0 = block_reduce_sum(c0, sh); c1 = block_reduce_sum(c1, sh); t = block_reduce_sum(t, sh);
+    if (threadIdx.x == 0) {
+        const float T = temperature[0];
+        const float temp = fminf(fmaxf(T, 0.001f), 0.5f);
+        out[0] = 0.5f * l / N1;
+        out[1] = c0 / N1;
+        out[2] = c1 / N1;
+        out[3] = (T >= 0.001f && T <= 0.5f) ? -0.5f * t / (temp * temp) : 0.f;
+    }
+}
+
+// The loss head's backward preparation in ONE launch: up to six fp32 matrices are transposed (32 x 32 LDS tiles), the ones flagged `scale`
+// are multiplied by alpha * scalar[0] on the way - in the transposed copy AND in place - and y0[0] = scalar[0] * x0[0].  (The fp32
+// GEMM kernel contracts row . row: its transposed operands are made here, together with the upstream-gradient scale the round-3 loss head
+// applied in separate passes.)
+struct TransposeJob { const float* in; float* out; int R, C, scale, tiles_c, tile0; };
+struct TransposeJobs { TransposeJob j[6]; int n; const float* scalar; float alpha; const float* x0; float* y0; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs J) {
+    __shared__ float t[32][33];
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].tile0) ++k;
+    const TransposeJob jb = J.j[k];
+    const int tile = blockIdx.x - jb.tile0;
+    const int c0 = (tile % jb.tiles_c) * 32, r0 = (tile / jb.tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float f = jb.scale ? J.alpha * J.scalar[0] : 1.0f;
+    float* inw = const_cast<float*>(jb.in);
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < jb.R && c0 + tx < jb.C) {
+            const float v = jb.in[(long)(r0 + j) * jb.C + c0 + tx] * f;
+            t[j][tx] = v;
+            if (jb.scale) inw[(long)(r0 + j) * jb.C + c0 + tx] = v;
+        }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < jb.C && r0 + tx < jb.R) jb.out[(long)(c0 + j) * jb.R + r0 + tx] = t[tx][j];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && J.y0) J.y0[0] = J.scalar[0] * J.x0[0];
 }
 
 // y[r,:] = x[r,:] * (one_minus ? 1 - s[r] : s[r]) * alpha
@@ -331,6 +384,41 @@ extern "C" int simseg_nce_rows(float* sims, const float* temperature, const floa
     hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, STREAM, row_loss, row_correct, row_tdot, ignore_mask, temperature,
                        out3, (int)N1);
     SS_LAUNCH_CHECK("nce_rows");
+    return 0;
+}
+
+extern "C" int simseg_nce_pair(float* sims2, const float* temperature, float* row_scratch, float* out4, int64_t N1, int64_t N2, int64_t target0,
+                               float smoothing, int write_grad, void* stream) {
+    SS_CHECK(sims2 && temperature && row_scratch && out4, "nce_pair: null pointer");
+    SS_CHECK(N1 > 0 && N2 > 0 && target0 >= 0 && target0 + N1 <= N2, "nce_pair: targets [%lld, %lld) outside [0, %lld)",
+             (long long)target0, (long long)(target0 + N1), (long long)N2);
+    float* rl = row_scratch; float* rc = rl + 2 * N1; float* rt = rc + 2 * N1;
+    hipLaunchKernelGGL(nce_rows_kernel, dim3((unsigned)(2 * N1)), dim3(256), 0, STREAM, sims2, temperature, (const float*)nullptr, rl, rc, rt, (int)N1,
+                       (int)N2, (int)target0, smoothing, write_grad);
+    hipLaunchKernelGGL(nce_finalize_pair_kernel, dim3(1), dim3(256), 0, STREAM, rl, rc, rt, temperature, out4, (int)N1);
+    SS_LAUNCH_CHECK("nce_pair");
+    return 0;
+}
+
+extern "C" int simseg_transpose_multi(const void* const* in, void* const* out, const int64_t* rows, const int64_t* cols, const int32_t* scale,
+                                      int64_t n, const float* scalar, float alpha, const float* x0, float* y0, void* stream) {
+    SS_CHECK(in && out && rows && cols && scale && n >= 1 && n <= 6, "transpose_multi: 1..6 jobs");
+    TransposeJobs J;
+    memset(&J, 0, sizeof(J));
+    int tile0 = 0, any = 0;
+    for (int k = 0; k < (int)n; ++k) {
+        SS_CHECK(in[k] && out[k] && rows[k] > 0 && cols[k] > 0, "transpose_multi: job %d is empty", k);
+        TransposeJob& j = J.j[k];
+        j.in = (const float*)in[k]; j.out = (float*)out[k]; j.R = (int)rows[k]; j.C = (int)cols[k]; j.scale = scale[k];
+        j.tiles_c = (j.C + 31) / 32; j.tile0 = tile0;
+        tile0 += j.tiles_c * ((j.R + 31) / 32);
+        any |= scale[k];
+    }
+    SS_CHECK(!(any || y0) || scalar, "transpose_multi: a scaled job needs the scalar");
+    SS_CHECK(!y0 || x0, "transpose_multi: y0 needs x0");
+    J.n = (int)n; J.scalar = scalar; J.alpha = alpha; J.x0 = x0; J.y0 = y0;
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)tile0), dim3(256), 0, STREAM, J);
+    SS_LAUNCH_CHECK("transpose_multi");
     return 0;
 }
 

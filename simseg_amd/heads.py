@@ -147,6 +147,82 @@ class NCEFn(Function):
         return df1, df2, dt, None, None, None, None
 
 
+class ClipLossFn(Function):
+    """The whole loss head of CLIPModel.forward_loss (pipelines/clip.py:129-140) as ONE autograd node: 0.5 * (NCE(image, text) +
+    NCE(text, image)) with the global-batch exchange inside (mml_loss.py:56-77: all-gather of the other modality's embeddings forward,
+    reduce-scatter of their gradients backward - GatherLayer's arithmetic).  Same kernels as NCEFn (exact fp32 MFMA similarity blocks,
+    in-place cross-entropy rows), fewer launches: forward = two GEMMs + one rows launch over both blocks + one finalize; backward = one
+    launch that scales both gradient blocks by the upstream gradient and makes every transposed GEMM operand, then four GEMMs (the
+    second of each pair accumulating into the first's result when there is one rank).  The round-3 head took ~14 + ~22 launches with
+    ~160 us holes between 4-11 us kernels.  Returns (loss, i2t acc, t2i acc)."""
+
+    @staticmethod
+    def forward(ctx, img, txt, temperature, group, rank, smoothing, gather_backward):
+        img32, txt32 = img.contiguous().float(), txt.contiguous().float()
+        world = dist.get_world_size(group) if group is not None else 1
+        if world > 1:
+            img_g = _take_prefetched(img, group)
+            txt_g = _take_prefetched(txt, group)
+            if img_g is None:
+                img_g = torch.empty(_gathered_shape(img32, world), device=img.device, dtype=F32)
+                dist.all_gather_into_tensor(img_g, img32, group=group)
+            if txt_g is None:
+                txt_g = torch.empty(_gathered_shape(txt32, world), device=txt.device, dtype=F32)
+                dist.all_gather_into_tensor(txt_g, txt32, group=group)
+            img_g, txt_g = img_g.float(), txt_g.float()
+        else:
+            img_g, txt_g = img32, txt32
+        Bl, Bg = img32.shape[0], img_g.shape[0]
+        sims = torch.empty(2, Bl, Bg, device=img.device, dtype=F32)
+        ops.gemm(img32, txt_g, out=sims[0])
+        ops.gemm(txt32, img_g, out=sims[1])
+        need = any(ctx.needs_input_grad[:3])
+        out4 = ops.nce_pair(sims, temperature.detach().reshape(1).float(), rank * Bl, smoothing, write_grad=need)
+        ctx.group, ctx.world, ctx.rank, ctx.gb = group, world, rank, gather_backward
+        ctx.save_for_backward(sims if need else None, img32, txt32, img_g if world > 1 else None, txt_g if world > 1 else None, out4)
+        loss, a1, a2 = out4[0].clone(), out4[1].clone(), out4[2].clone()
+        ctx.mark_non_differentiable(a1, a2)
+        return loss, a1, a2
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        ds, img32, txt32, img_g, txt_g, out4 = ctx.saved_tensors
+        world = ctx.world
+        g = gloss.contiguous().float().reshape(1)
+        need_img, need_txt, need_t = ctx.needs_input_grad[:3]
+        x0 = out4[3:4] if need_t else None
+        # ONE launch: both gradient blocks times 0.5 * g (in place and transposed) + the transposed embeddings; dT * g on the way
+        if world == 1:
+            (dsi_t, dst_t, txt_t, img_t), dt = ops.transpose_multi([ds[0], ds[1], txt32, img32], [1, 1, 0, 0], scalar=g, alpha=0.5, x0=x0)
+            txtg_t, imgg_t = txt_t, img_t
+        else:
+            (dsi_t, dst_t, txtg_t, imgg_t, txt_t, img_t), dt = ops.transpose_multi([ds[0], ds[1], txt_g, img_g, txt32, img32], [1, 1, 0, 0, 0, 0],
+                                                                                    scalar=g, alpha=0.5, x0=x0)
+        dimg = dtxt = None
+        through_gather = world == 1 or ctx.gb          # (one rank: the "gathered" embeddings are the local ones, gradients flow through both roles)
+        if need_img:
+            dimg = ops.gemm(ds[0], txtg_t)                                   # dS_i . txt_g          [Bl, P]
+            if through_gather:
+                if world == 1:
+                    ops.gemm(dst_t, txt_t, out=dimg, accumulate=True)        # + dS_t^T . txt
+                else:
+                    dimg_g = ops.gemm(dst_t, txt_t)                          # [Bg, P]: every rank's rows; this rank keeps the sum of its own
+                    own = torch.empty_like(dimg)
+                    dist.reduce_scatter_tensor(own, dimg_g, op=dist.ReduceOp.SUM, group=ctx.group)
+                    dimg = dimg + own
+        if need_txt:
+            dtxt = ops.gemm(ds[1], imgg_t)                                   # dS_t . img_g
+            if through_gather:
+                if world == 1:
+                    ops.gemm(dsi_t, img_t, out=dtxt, accumulate=True)        # + dS_i^T . img
+                else:
+                    dtxt_g = ops.gemm(dsi_t, img_t)
+                    own = torch.empty_like(dtxt)
+                    dist.reduce_scatter_tensor(own, dtxt_g, op=dist.ReduceOp.SUM, group=ctx.group)
+                    dtxt = dtxt + own
+        return dimg, dtxt, (dt.reshape(()) if need_t else None), None, None, None, None
+
+
 def patch_text_similarity(patch_proj, text_feat, eps=1e-12, compute_dtype=F32):
     """sim[b,n,c] = <normalize(patch_proj[b,n,:]), text_feat[c,:]>  -- the dense zero-shot segmentation map
     (tools/seg_evaluation.py:112 F.normalize + :136 per-class GEMV, here for every class at once).

@@ -371,6 +371,35 @@ def nce_rows(sims, temperature, target0, ignore_mask=None, smoothing=0.0, write_
     return out3
 
 
+def nce_pair(sims2, temperature, target0, smoothing=0.0, write_grad=True):
+    """Both directions at once (include/simseg_hip.h simseg_nce_pair): sims2 [2, N1, N2] fp32, in place -> gradients w.r.t. the
+    similarities.  Returns out4 = [loss, i2t acc, t2i acc, dLoss/dT] (device tensor)."""
+    require_gpu(sims2)
+    _, N1, N2 = sims2.shape
+    scratch = torch.empty(6 * N1, device=sims2.device, dtype=torch.float32)
+    out4 = torch.empty(4, device=sims2.device, dtype=torch.float32)
+    call("simseg_nce_pair", ptr(_c(sims2)), ptr(temperature), ptr(scratch), ptr(out4), N1, N2, int(target0), float(smoothing), int(write_grad), stream())
+    return out4
+
+
+def transpose_multi(mats, scale_flags, scalar=None, alpha=1.0, x0=None):
+    """Transposes of up to six contiguous fp32 matrices in ONE launch; matrices whose flag is set are multiplied by alpha * scalar[0] in
+    the copy and in place.  Returns (list of transposed tensors, scalar[0] * x0[0] as a 1-element tensor or None)."""
+    import ctypes
+    n = len(mats)
+    for m in mats:
+        require_gpu(m)
+        if m.dtype != torch.float32 or m.dim() != 2:
+            raise TypeError("transpose_multi: contiguous fp32 matrices")
+        _c(m)
+    outs = [torch.empty(m.shape[1], m.shape[0], device=m.device, dtype=torch.float32) for m in mats]
+    y0 = torch.empty(1, device=mats[0].device, dtype=torch.float32) if x0 is not None else None
+    PT, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    call("simseg_transpose_multi", PT(*[m.data_ptr() for m in mats]), PT(*[o.data_ptr() for o in outs]), I64(*[m.shape[0] for m in mats]),
+         I64(*[m.shape[1] for m in mats]), I32(*[int(bool(f)) for f in scale_flags]), n, ptr(scalar), float(alpha), ptr(x0), ptr(y0), stream())
+    return outs, y0
+
+
 def scale_rows(x, s=None, one_minus=False, alpha=1.0, out=None):
     require_gpu(x)
     if out is None:

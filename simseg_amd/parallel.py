@@ -26,6 +26,7 @@ class GradSync:
     def __init__(self, params, group=None, average=True, overlap=True, bucket_mb=64):
         self.params = [p for p in params if p.requires_grad]
         self.group, self.average, self.overlap = group, average, overlap
+        self.grad_scale = 1.0
         dev = self.params[0].device
         # backward order ~ reverse registration order (heads, text tower, image tower for the CLIP model)
         order = list(reversed(range(len(self.params))))
@@ -130,7 +131,10 @@ class GradSync:
                 w.wait()                           # the current stream waits for the collective (RCCL: no host block)
             if self.flat.is_cuda and self._comm is not None:
                 torch.cuda.current_stream().wait_stream(self._comm)
-        if world > 1 and self.average:
+        # average = "defer": the division by the world size is left to the optimizer kernel (AdamW.step(grad_scale=sync.grad_scale)) -
+        # one pass over 0.8 GB of gradients less per step
+        self.grad_scale = 1.0 / world if (world > 1 and self.average == "defer") else 1.0
+        if world > 1 and self.average and self.average != "defer":
             self.flat.div_(world)
         for p, v in zip(self.params, self.views):
             p.grad = v

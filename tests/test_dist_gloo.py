@@ -74,7 +74,8 @@ def _worker(rank, world, port, q):
     res["gsync"] = ([g_.tolist() for g_ in local], [p.grad.tolist() for p in lin.parameters() if p.requires_grad],
                     all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views)))
     # the same exchange without overlap (one flat all-reduce after the backward) and with two small buckets: identical means
-    for kw in (dict(overlap=False), dict(overlap=True, bucket_mb=0)):
+    # (average="defer": the sum is delivered and the division by the world size is handed to the optimizer kernel as grad_scale)
+    for kw in (dict(overlap=False), dict(overlap=True, bucket_mb=0), dict(overlap=True, average="defer")):
         lin2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
         lin2.load_state_dict(lin.state_dict())
         s2 = GradSync(lin2.parameters(), **kw)
@@ -83,7 +84,8 @@ def _worker(rank, world, port, q):
                 p_.grad = None
             lin2(x).square().sum().backward()
             s2.finish()
-        res.setdefault("gsync_alt", []).append([p.grad.tolist() for p in lin2.parameters()])
+        assert s2.grad_scale == (0.5 if kw.get("average") == "defer" else 1.0)
+        res.setdefault("gsync_alt", []).append([(p.grad * s2.grad_scale).tolist() for p in lin2.parameters()])
     # a second backward before finish(): the overlapped exchange refuses it (its buckets are already reduced) instead of racing
     s3 = GradSync(lin.parameters(), overlap=True)
     lin(x).square().sum().backward()

@@ -110,16 +110,23 @@ def _miou(hist3):
     return iou * 100.0, float(np.nanmean(iou) * 100.0)
 
 
-@pytest.mark.parametrize("case", ["tiny_288", "vit_s_288"])
+@pytest.mark.parametrize("case", ["tiny_288", "vit_s_288", "vit_b_512_c171"])
 def test_miou_gate_hip_pipeline_vs_oracle_loop(case, monkeypatch):
     from oracle import segpost_ref as SR
     from oracle import simseg_ref as R
     from simseg_amd import segpost
+    S, C, top = 288, 21, 10
     if case == "tiny_288":
         vit, vdim, bert, bdim, B = "vit_test_patch16", 128, "bert-test", 128, 5
-    else:
+    elif case == "vit_s_288":
         vit, vdim, bert, bdim, B = "vit_small_patch16_224_in21k", 384, "bert-test", 128, 2
-    S, C, top = 288, 21, 10
+    else:
+        # BASELINE configs[3] scale: ViT-B/16 on 512^2 windows (1025 tokens: the exact-mode attention through the bf16 pieces, the split-bf16
+        # GEMMs), 171 COCO-Stuff-shaped classes, the tool's top_cls_num for everything but PASCAL Context (tools/seg_evaluation.py:247);
+        # the CRF at 512^2 (tile-major order, chunks, the front hash table's spill path).  Two windows: ~2 minutes of host time for the oracle loop.
+        vit, vdim, bert, bdim, B = "vit_base_patch16_224_in21k", 768, "bert-test", 128, 2
+        S, C, top = 512, 171, 10
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
     u8, x = _voc_like(B, S, seed=17)
     g = torch.Generator().manual_seed(3)
     text = torch.nn.functional.normalize(torch.randn(C, 512, generator=g), dim=-1)

@@ -261,6 +261,34 @@ def test_bert_qkv_operand_is_read_in_place_and_gradscaler_protocol(golden, monke
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("Bl,P,smoothing", [(8, 512, 0.0), (512, 512, 0.0), (96, 256, 0.1)])
+def test_fused_loss_head_equals_the_two_nce_calls(golden, monkeypatch, Bl, P, smoothing):
+    """CLIPModel.forward_loss through the fused head (NCE.both -> heads.ClipLossFn: both directions, one autograd node, 4 + 5 launches)
+    against the reference's structure - two NCE calls and 0.5 * (a + b) (pipelines/clip.py:129-140) - on the same embeddings: loss,
+    both accuracies and the gradients w.r.t. the image embeddings, the text embeddings and the temperature."""
+    from simseg_amd import ops
+    m = _build(golden, extra=[f"loss.smoothing={smoothing}"] if smoothing else [])
+    nce = m.loss
+    assert nce.smoothing == smoothing
+    g = torch.Generator(device="cuda").manual_seed(Bl)
+    base_i = torch.nn.functional.normalize(torch.randn(Bl, P, device="cuda", generator=g), dim=-1)
+    base_t = torch.nn.functional.normalize(base_i + 0.7 * torch.nn.functional.normalize(torch.randn(Bl, P, device="cuda", generator=g), dim=-1), dim=-1)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SIMSEG_AMD_FUSED_LOSS", fused)
+        img, txt = base_i.clone().requires_grad_(True), base_t.clone().requires_grad_(True)
+        nce.temperature.grad = None
+        n0 = len(ops.LAUNCHES) if hasattr(ops, "LAUNCHES") else 0
+        loss_dict, a1, a2 = m.forward_loss(img, txt)
+        (loss_dict["nce_loss"] * 3.0).backward()
+        res.append((loss_dict["nce_loss"].item(), a1.item(), a2.item(), img.grad.clone(), txt.grad.clone(), nce.temperature.grad.clone()))
+    (l1, p1, q1, gi1, gt1, gT1), (l0, p0, q0, gi0, gt0, gT0) = res
+    assert abs(l1 - l0) <= 1e-6 * abs(l0) and p1 == p0 and q1 == q0, (l1, l0, p1, p0, q1, q0)
+    for a, b, what in ((gi1, gi0, "image embeddings"), (gt1, gt0, "text embeddings"), (gT1, gT0, "temperature")):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+        assert err < 2e-5, (what, err)
+
+
 def test_training_step_with_host_caption_lengths_has_no_host_synchronisation(golden, monkeypatch):
     """batch["caption_lengths"] (host numbers, what a loader's tokenizer returned): the text tower sizes its packed rows from them, one
     kernel builds the row maps, and NOTHING in forward + loss + backward reads the device - asserted with torch's sync-debug mode (nonzero /
