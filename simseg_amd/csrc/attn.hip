@@ -1116,6 +1116,246 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 forward, ViT-B training shape (128 < T <= 256, no mask, no dropout): PERSISTENT form with a loader wave (round 4).
+// The resident kernel above is one block per head: copy K / V (50 KB at T = 197) -> wait -> 2 query passes -> store, three such blocks per
+// CU at independent phases.  Measured (profiles/r2_attn_fwd_ablation.txt): its copies alone take 150 us, its tile loops alone 164 us, the
+// kernel 214 us - a block that computes has no copies in flight and a CU's HBM share is proportional to what it has in flight, so most
+// of one component is exposed.  Here ONE block per CU walks its heads: wave q32 only issues global -> LDS copies (the next head's K and V
+// into the other LDS stage, all 2 * rows8 / 8 pieces at once) and waits for them; waves 0 .. q32-1 own one 32-query tile each of the
+// CURRENT head - one pass instead of two, no second Q load, 7 of 8 waves busy instead of 7 of 8 passes - with the next head's Q rows
+// requested into a second register set at the start of the head.  One barrier per head hands the stages over.  A head's copies have the
+// whole tile loop of the previous head to land: the copy stream never stops, the matrix / VALU pipes never wait for it.
+// ------------------------------------------------------------------------------------------------
+constexpr int PERS_MAXT = 224;       // 7 compute waves + the loader = 8 waves = two per SIMD: the whole 256-register budget per wave
+
+__host__ __device__ inline int pers_stage_bytes(int T) { return 2 * ((T + 7) & ~7) * 128; }
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(512) void attn_fwd_bf16_pers_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    const int T = p.T;
+    const long RS = 3L * p.H * 64;
+    const int HD = p.H * 64;
+    const int nt = (T + KT - 1) / KT, q32 = (T + 31) / 32;
+    const int rows8 = res_rows8(T), np = rows8 >> 3;
+    const int stage_bytes = 2 * rows8 * 128;
+    const int nheads = p.B * p.H;
+    const int mine = (nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads blockIdx.x, + gridDim.x, ...
+    const bool loader = wave == q32;
+    const bf16_t* qkv = static_cast<const bf16_t*>(p.qkv);
+
+    auto issue = [&](int hd, int st) {             // the loader's: every piece of head hd's K (pieces 0..np-1) and V into stage st
+        const int b = hd / p.H, h = hd % p.H;
+        const bf16_t* base = qkv + (long)b * T * RS + h * 64;
+        char* dstK = lds + st * stage_bytes;
+        char* dstV = dstK + rows8 * 128;
+        for (int piece = 0; piece < 2 * np; ++piece) {
+            const int isv = piece >= np;
+            const int pp = isv ? piece - np : piece;
+            const int r = pp * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (isv ? v_swz(r) : k_swz(r));
+            const int key = r < T ? r : T - 1;
+            const bf16_t* src = base + (long)key * RS + (isv + 1) * HD + c * 8;
+            // (from inline asm: through the builtin the compiler knows that LDS writes are in flight somewhere in this kernel and puts
+            //  s_waitcnt vmcnt(0) in front of every transposed V read of the COMPUTE waves - draining their output stores and their Q
+            //  requests once per tile; the loader's own wait in front of the head barrier is the only one that is needed)
+            const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)((isv ? dstV : dstK) + pp * 1024));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory");
+        }
+    };
+    bf16x8 qr[4];
+    auto load_q = [&](int hd, bf16x8 (&dst)[4]) {  // a compute wave's: its 32 query rows of head hd (rows >= T: row T-1, never stored)
+        const int b = hd / p.H, h = hd % p.H;
+        const bf16_t* base = qkv + (long)b * T * RS + h * 64;
+        const int q = wave * 32 + ql;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            // (plain loads: the compiler then puts s_waitcnt vmcnt(0) in front of the first MFMA that reads these registers, which also
+            //  drains the previous head's output stores.  Requesting them from inline asm instead - invisible to the wait counting, with
+            //  the loop's counted wait covering them - produced NaNs: the compiler believes an asm output is valid at once and moved
+            //  the registers before the data had landed.)
+            union { u32x4 v; bf16x8 hh; } u;
+            u.v = *reinterpret_cast<const u32x4*>(base + (long)min(q, T - 1) * RS + (2 * kk + h2) * 8);
+            dst[kk] = u.hh;
+        }
+    };
+    if (mine <= 0) return;
+    // (p.dbg: timing ablations with WRONG results - 41 = no tile loop, 42 = no K / V copies, 43 = no output stores: tools/attn_fwd_ab.py)
+    if (loader) { if (p.dbg != 42) issue(blockIdx.x, 0); }
+    else load_q(blockIdx.x, qr);
+
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int krow = ql * 128, ksw = k_swz(ql);
+    const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
+    const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
+
+#pragma unroll 1
+    for (int i = 0; i < mine; ++i) {
+        const int hd = blockIdx.x + i * gridDim.x;
+        const int st = i & 1;
+        // everything requested for head i (the loader's copies; this wave's Q rows) has landed before the barrier; behind it the other
+        // stage - head i-1's - is free
+        // (compute waves, from the second head on: the 4 Q requests are OLDER than the previous head's 8 output stores + 1 lse store, and
+        //  vmcnt retires in order - waiting for "at most 9 / 8 outstanding" leaves the stores in flight across the barrier.  A full drain here
+        //  exposed the stores' acknowledgement latency once per head: 228 vs 147 us for the layer, tools/attn_fwd_ab.py.)
+        if (loader || i == 0 || p.dbg == 43) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (p.lse) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // (the bare barrier: __syncthreads() is a fence + barrier and drains vmcnt again)
+        __builtin_amdgcn_sched_barrier(0);
+        if (loader) {
+            if (i + 1 < mine && p.dbg != 42) issue(hd + gridDim.x, st ^ 1);
+            continue;
+        }
+        const char* ldsK = lds + st * stage_bytes;
+        const char* ldsV = ldsK + rows8 * 128;
+        const int b = hd / p.H, h = hd % p.H;
+        const int q = wave * 32 + ql;
+        f32x16 o[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ii][r] = 0.f;
+        float m = NEG, lsum = 0.f;
+        // Software pipeline over the key tiles (two score register sets): while the VALU works through tile it's softmax, the matrix pipe
+        // forms tile it+1's scores from fragments requested a stage earlier - a lone wave spent a third of its cycles in s_waitcnt (LDS round
+        // trips in front of the first score MFMA and behind the maximum's cross-lane exchange) and a quarter stalled at issue
+        // (profiles/r2_pmc_attn_fwd_resident.txt); with two waves per SIMD there is nobody else to fill those holes.
+        auto load_kf = [&](int it, bf16x8 (&kf)[8], auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            const int kv0 = it * KT;
+            const char* sk = ldsK + kv0 * 128;
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                if (!EDGE) {
+                    kf[ii] = ld_bf16x8(sk + (ii >> 2) * 32 * 128 + krow + (((2 * (ii & 3) + h2) ^ ksw) << 4));
+                } else {
+                    int r = kv0 + (ii >> 2) * 32 + ql;
+                    r = r < rows8 ? r : rows8 - 1;
+                    kf[ii] = ld_bf16x8(ldsK + r * 128 + (((2 * (ii & 3) + h2) ^ k_swz(r)) << 4));
+                }
+            }
+        };
+        auto load_vf = [&](int it, bf16x8 (&vf)[8], auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            const int kv0 = it * KT;
+            const char* sv = ldsV + kv0 * 128;
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {     // ii = kb*4 + s2*2 + db
+                if (!EDGE) {
+                    const int roff = ((ii >> 2) * 32 + 16 * ((ii >> 1) & 1)) * 128 + vrow;
+                    const int coff = ((((ii & 1) * 4 + vch) ^ vsw) << 4) + vsub;
+                    vf[ii] = tr_frag(sv + roff + coff, 8 * 128);
+                } else {
+                    const int r0 = kv0 + (ii >> 2) * 32 + 16 * ((ii >> 1) & 1) + 4 * h2 + (a16 >> 2);
+                    const int ra = r0 < rows8 ? r0 : rows8 - 1, rb = r0 + 8 < rows8 ? r0 + 8 : rows8 - 1;
+                    const char* pa = ldsV + ra * 128 + ((((ii & 1) * 4 + vch) ^ v_swz(ra)) << 4) + vsub;
+                    const char* pb = ldsV + rb * 128 + ((((ii & 1) * 4 + vch) ^ v_swz(rb)) << 4) + vsub;
+                    union { struct { s16x4 lo, hi; } hh; bf16x8 v; } u;
+                    u.hh.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa));
+                    u.hh.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
+                    vf[ii] = u.v;
+                }
+            }
+        };
+        auto scores = [&](const bf16x8 (&kf)[8], f32x16 (&s)[2]) {      // (both 32-key blocks always: a branch per MFMA would end the scheduling region;
+#pragma unroll                                                          //  an all-padding block of the last tile costs four MFMAs once per head)
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s[0] = SS_MFMA_32x32x16(kf[kk], qr[kk], s[0], 0, 0, 0);
+                s[1] = SS_MFMA_32x32x16(kf[4 + kk], qr[kk], s[1], 0, 0, 0);
+            }
+        };
+        auto pv = [&](const bf16x8 (&vf)[8], const f32x16 (&s)[2], bool two) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !two) break;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kb][8 * s2 + e];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        o[db] = SS_MFMA_32x32x16(vf[kb * 4 + s2 * 2 + db], pf, o[db], 0, 0, 0);
+                }
+            }
+        };
+        const int kvl = (nt - 1) * KT;
+        const bool two_last = kvl + 32 < T;         // the last tile's second 32-key block holds keys
+        f32x16 sc[2], sn[2];
+        bf16x8 kf[8], vf[8];
+        if (nt == 1) load_kf(0, kf, std::true_type{}); else load_kf(0, kf, std::false_type{});
+        scores(kf, sc);
+        if (p.dbg != 41) {
+#pragma unroll 1
+        for (int it = 0; it + 2 < nt; ++it) {        // tiles it and it+1 interior: tile it+1's scores are formed beside tile it's softmax
+            load_vf(it, vf, std::false_type{});
+            load_kf(it + 1, kf, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            scores(kf, sn);
+            softmax_tile_lean<false, false>(sc, nullptr, h2, p.scale_log2e, m, lsum, o, KT);
+            pv(vf, sc, true);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sc[kb] = sn[kb];
+        }
+        if (nt > 1) {                                 // tile nt-2 (interior) beside the scores of the last, partial tile
+            load_vf(nt - 2, vf, std::false_type{});
+            load_kf(nt - 1, kf, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            scores(kf, sn);
+            softmax_tile_lean<false, false>(sc, nullptr, h2, p.scale_log2e, m, lsum, o, KT);
+            pv(vf, sc, true);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sc[kb] = sn[kb];
+        }
+        }
+        // the head's last scores are formed: Q of the NEXT head replaces it (lands under the last tile's softmax / PV, the stores and the barrier)
+        if (i + 1 < mine) load_q(hd + gridDim.x, qr);
+        load_vf(nt - 1, vf, std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        softmax_tile_lean<false, true>(sc, nullptr, h2, p.scale_log2e, m, lsum, o, T - kvl, two_last);
+        pv(vf, sc, two_last);
+        const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (q < T && p.dbg != 43) {
+            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * T + q) * HD + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = db * 32 + 8 * r4 + 4 * h2;
+                    bf16x4 v = {(bf16_t)(o[db][4 * r4] * inv), (bf16_t)(o[db][4 * r4 + 1] * inv), (bf16_t)(o[db][4 * r4 + 2] * inv), (bf16_t)(o[db][4 * r4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + d) = v;
+                }
+            if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m + log2f(ltot);
+        }
+    }
+}
+
+int launch_fwd_pers(const AttnParams& p, hipStream_t stream) {
+    static bool configured = false;
+    static int ncu = 256;
+    auto kern = attn_fwd_bf16_pers_kernel<0>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pers_stage_bytes(PERS_MAXT));
+        if (e != hipSuccess) return simseg_set_error("attention_fwd: cannot reserve LDS: %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        configured = true;
+    }
+    const int q32 = (p.T + 31) / 32;
+    const int nheads = p.B * p.H;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nheads < ncu ? nheads : ncu)), dim3((q32 + 1) * 64), 2 * pers_stage_bytes(p.T), stream, p);
+    return 0;
+}
+
 __host__ int res_smem(int T, bool mask) { return 2 * ((T + 7) & ~7) * 128 + (mask ? ((T + KT - 1) / KT) * KT * 4 : 0); }
 
 template <bool DROP, bool MASK>
@@ -2232,7 +2472,12 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
     if (dtype == 0)
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
-    else if ((T <= RES_AUTO_T || (g_attn_variant >= 2 && T <= RES_MAXT)) && g_attn_variant != 1) {
+    else if (T > 128 && T <= PERS_MAXT && !p.mask && !p.drop_thresh && !p.pack && (g_attn_variant == 4 || (g_attn_variant >= 40 && g_attn_variant <= 49))) {
+        // the persistent loader-wave kernel: OPT-IN (variant 4; 41-43 = its timing ablations).  Measured slower than the one-block-per-head
+        // resident kernel at the ViT-B training shape (223 vs 177 us, tools/attn_fwd_ab.py) - see the notes at the kernel
+        const int rc = launch_fwd_pers(p, (hipStream_t)stream);
+        if (rc) return rc;
+    } else if ((T <= RES_AUTO_T || (g_attn_variant >= 2 && T <= RES_MAXT)) && g_attn_variant != 1) {
         int rc;
         if (p.drop_thresh) rc = launch_fwd_res<true, true>(p, (hipStream_t)stream);
         else if (p.mask) rc = launch_fwd_res<false, true>(p, (hipStream_t)stream);

@@ -775,6 +775,27 @@ def test_attention_bwd_qkv_bias_gradient(ops, T):
             _close(cs, want, 2e-5, f"qkv bias gradient, ragged mask, skip_padded_rows={skip} T={T}")
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 197, 4), (70, 145, 12), (40, 224, 3), (2, 130, 2)])
+def test_attention_fwd_persistent_loader_wave_kernel(ops, B, T, H):
+    """The opt-in persistent forward (attention variant 4: one block per CU walks its heads, a loader wave copies the next head's K / V
+    into the other LDS stage, the compute waves software-pipeline their key tiles) computes the bits of the default resident kernel - more
+    heads than blocks included - and both agree with the fp64 softmax attention."""
+    qkv = _rand(B, T, 3 * H * 64, seed=T, dtype=torch.bfloat16)
+    try:
+        ops.set_attention_variant(4)
+        out4, lse4 = ops.attention_fwd(qkv, H, None, scale=0.125, save_lse=True)
+        ops.set_attention_variant(0)
+        out0, lse0 = ops.attention_fwd(qkv, H, None, scale=0.125, save_lse=True)
+    finally:
+        ops.set_attention_variant(0)
+    assert torch.equal(lse4, lse0)
+    # (the persistent kernel forms all eight score MFMAs of the partial last tile; the masked block's probabilities are exactly 0 either way)
+    assert torch.equal(out4, out0)
+    q, k, v = [t.view(B, T, H, 64).transpose(1, 2).double() for t in qkv.chunk(3, -1)]
+    want = ((q @ k.transpose(-1, -2) * 0.125).softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+    assert float((out4.double() - want).abs().max()) < 2e-2
+
+
 def test_attention_masked_length_limit(ops):
     qkv = _rand(1, 1100, 3 * 64, seed=1, dtype=torch.bfloat16)
     mask = torch.ones(1, 1100, dtype=torch.long, device="cuda")
