@@ -285,11 +285,13 @@ int simseg_seg_predict(const void* masks, const int* cand_idx, const float* cand
  * rgb [B,H,W,3] bytes (the de-normalised network inputs, RGB order), prob [B,C,H,W] fp32 in [0,1] (C <= 8 candidate maps per image:
  * an image's maps share its lattices; the images of a batch are independent problems solved side by side in the same launches) ->
  * mask [B,C,H,W] bytes (255 where the pixel is labelled as the class); q_out (optional) [B,C,H,W] fp32 = Q(label 1) after the last
- * iteration.  workspace: caller-allocated, 256-byte aligned, simseg_dense_crf_workspace_bytes(B, H, W, C). */
+ * iteration.  workspace: caller-allocated, 256-byte aligned, simseg_dense_crf_workspace_bytes(B, H, W, C).  reuse_spatial != 0: the caller
+ * vouches that the previous call on this workspace had the same H, W and sxy_g and that the workspace is untouched since - the spatial
+ * (Gaussian) lattice, which depends on nothing else, is then not rebuilt. */
 int64_t simseg_dense_crf_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t C);
 int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t B, int64_t C, int64_t H, int64_t W, float sxy_g,
                      float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace, int64_t workspace_bytes,
-                     void* stream);
+                     int reuse_spatial, void* stream);
 
 /* debug: bf16 attention forward that also writes a 5-entry cycle-counter timeline of block (0,0) to dbg (tools/dbg_attn_timeline.py). */
 int simseg_debug_attention_timeline(const void* qkv, void* out, float* lse, void* dbg, int64_t B, int64_t T, int64_t H, void* stream);

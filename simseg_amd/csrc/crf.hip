@@ -564,6 +564,10 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
         lat[k].start = L.carve<int>(base, nv);
         lat[k].rec = L.carve<int2>(base, nv);
         lat[k].recs = L.carve<int2>(base, nv);
+        // the lattice's own point count and list cursor (64 ints: with everything above, the spatial lattice's region depends on the image
+        // size only - a later call on the same workspace can reuse it, see reuse_spatial)
+        lat[k].M = L.carve<int>(base, 64);
+        lat[k].cursor = lat[k].M ? lat[k].M + 1 : nullptr;
     }
     const long CS = C + 1 <= 4 ? 4 : 8;                          // channel stride (the C maps + the norm channel of the first filter, padded)
     const long vmax = (N * 6 + 1) * CS;
@@ -573,9 +577,7 @@ void crf_carve(CrfLayout& L, char* base, long N, long N1, int C, CrfLattice (&la
     u = L.carve<float>(base, N * CS * 2);
     fg = L.carve<float>(base, N * CS);
     fb = L.carve<float>(base, N * CS);
-    flags = L.carve<int>(base, 8);            // M of the two lattices, key overflow flag, -, entry cursors of the two lattices
-    lat[0].M = flags; lat[1].M = flags ? flags + 1 : nullptr;
-    lat[0].cursor = flags ? flags + 4 : nullptr; lat[1].cursor = flags ? flags + 5 : nullptr;
+    flags = L.carve<int>(base, 8);            // [2] = key overflow flag of the hash builds
 }
 
 unsigned crf_blocks(long work) {
@@ -621,6 +623,7 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
                float* val1, hipStream_t s, bool with_kn) {
     const long N = (long)nimg * H * W;
     const long nv = N * (D + 1);
+    (void)hipMemsetAsync(lt.M, 0, 2 * sizeof(int), s);          // point count + list cursor
     (void)hipMemsetAsync(lt.hkeys, 0xFF, (size_t)(lt.scap + lt.cap) * sizeof(unsigned long long), s);
     const CrfTable table{lt.hkeys, lt.hid, (unsigned)(lt.scap - 1), (unsigned)(lt.cap - 1)};
     hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, tw, 1.0f / sxy, 1.0f / srgb, table,
@@ -667,7 +670,7 @@ extern "C" int64_t simseg_dense_crf_workspace_bytes(int64_t B, int64_t H, int64_
 // (optional) [B,C,H,W] = Q(label 1).  The images of a batch are independent problems solved side by side in the same launches.
 extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* mask, float* q_out, int64_t B, int64_t C, int64_t H, int64_t W,
                                 float sxy_g, float compat_g, float sxy_b, float srgb, float compat_b, int iters, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+                                int64_t workspace_bytes, int reuse_spatial, void* stream) {
     SS_CHECK(rgb && prob && mask && workspace, "dense_crf: null pointer");
     SS_CHECK(B >= 1 && B < (1 << 14), "dense_crf: 1..16383 images per call (got %lld)", (long long)B);
     SS_CHECK(H > 0 && W > 0 && B * H * W < (1ll << 26), "dense_crf: batch of %lld images of %lld x %lld pixels is out of range", (long long)B,
@@ -696,8 +699,10 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     const int tw = (H % 16 == 0 && W % 16 == 0) ? (int)(W / 16) : 0;       // tile-major internal pixel order where the image tiles evenly
     // K(n) of each lattice - the filter of its norm, needed by the first update - is one more channel of the first iteration's filter
     // (4 filter applications per lattice and call instead of 5) whenever the C candidate channels leave room for it
+    // reuse_spatial: the caller vouches that the LAST call on this workspace had the same H, W and sxy_g and that nothing has written to the
+    // workspace since - the spatial lattice (hash tables, neighbour lists, entry lists, norm and K(norm)) is still there and is not rebuilt
     const bool ride = Ci + 1 <= CRF_MAXC;
-    crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s, !ride);
+    if (!reuse_spatial) crf_build<2>(lat[0], rgb, 1, (int)H, (int)W, tw, sxy_g, 1.0f, flags + 2, val0, val1, s, !ride);
     crf_build<5>(lat[1], rgb, (int)B, (int)H, (int)W, tw, sxy_b, srgb, flags + 2, val0, val1, s, !ride);
     const long nc = NT * Ci;
     const int CS = Ci + 1 <= 4 ? 4 : 8;                          // as in crf_carve
@@ -705,7 +710,7 @@ extern "C" int simseg_dense_crf(const uint8_t* rgb, const float* prob, uint8_t* 
     hipLaunchKernelGGL(crf_init_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, prob, q1, u, NT, N, Ci, CS, (int)W, tw);
     for (int it = 0; it < iters; ++it) {
         const bool first = ride && it == 0;
-        crf_filter<2>(lat[0], q1, true, lat[0].norm, fg, false, val0, val1, N, Ci, CS, 0, (int)B, s, first ? lat[0].kn : nullptr);
+        crf_filter<2>(lat[0], q1, true, lat[0].norm, fg, false, val0, val1, N, Ci, CS, 0, (int)B, s, (first && !reuse_spatial) ? lat[0].kn : nullptr);
         crf_filter<5>(lat[1], q1, true, lat[1].norm, fb, false, val0, val1, NT, Ci, CS, 0, 1, s, first ? lat[1].kn : nullptr);
         const bool last = it + 1 == iters;
         hipLaunchKernelGGL(crf_update_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, u, fg, fb, lat[0].kn, lat[1].kn, compat_g, compat_b,

@@ -518,6 +518,7 @@ def seg_predict(masks, cand_idx, cand_score, labels, num_classes, ignore_index=2
 
 
 _CRF_WS = {}
+_CRF_SPATIAL = {}      # (device, stream) -> (workspace address, H, W, sxy_g) of the spatial lattice that workspace holds
 
 
 def dense_crf(rgb, prob, sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_b=10.0, iters=3, want_q=False):
@@ -539,11 +540,17 @@ def dense_crf(rgb, prob, sxy_g=3.0, compat_g=3.0, sxy_b=40.0, srgb=13.0, compat_
     ws = _CRF_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         _CRF_WS.pop(key, None)
+        _CRF_SPATIAL.pop(key, None)
         ws = _CRF_WS[key] = torch.empty(nbytes, device=rgb.device, dtype=torch.uint8)
     mask = torch.empty(B, C, H, W, device=rgb.device, dtype=torch.uint8)
     q = torch.empty(B, C, H, W, device=rgb.device, dtype=torch.float32) if want_q else None
+    # the spatial (Gaussian) lattice depends on H, W and sxy only and lives at the head of the workspace: a call with the same three on the
+    # same workspace (this module owns it - nobody else writes there) finds it built
+    sig = (ws.data_ptr(), int(H), int(W), float(sxy_g))
+    reuse = _CRF_SPATIAL.get(key) == sig and os.environ.get("SIMSEG_CRF_SPATIAL_CACHE", "1") != "0"
     call("simseg_dense_crf", ptr(_c(rgb)), ptr(_c(prob)), ptr(mask), ptr(q), B, C, H, W, float(sxy_g), float(compat_g), float(sxy_b), float(srgb),
-         float(compat_b), int(iters), ptr(ws), nbytes, stream())
+         float(compat_b), int(iters), ptr(ws), nbytes, int(reuse), stream())
+    _CRF_SPATIAL[key] = sig
     if single:
         return mask[0], (q[0] if want_q else None)
     return mask, q

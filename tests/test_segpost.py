@@ -364,3 +364,36 @@ def test_crf_static_form_equals_chunked():
     static = segpost.crf_masks(p4, cand_idx, imgs, scale=16, static=True)
     agree = float((chunked == static).float().mean())
     assert agree >= 0.9995, agree                     # (fp32 sums in a different channel layout: a handful of boundary pixels at most)
+
+
+@pytest.mark.gpu
+def test_dense_crf_reuses_the_spatial_lattice_across_calls(monkeypatch):
+    """The spatial (Gaussian) lattice depends on (H, W, sxy) only: a second ops.dense_crf call on the same workspace finds it built
+    (simseg_dense_crf reuse_spatial) and returns bit-equal masks and marginals; another image size rebuilds it; the cache can be
+    switched off.  Different images and candidate counts between the calls: nothing of the first call's bilateral lattice may leak."""
+    from simseg_amd import ops
+    rng = np.random.default_rng(0)
+
+    def scene(B, C, S, seed):
+        g = torch.Generator().manual_seed(seed)
+        img = (torch.rand(B, S, S, 3, generator=g) * 255).to(torch.uint8).cuda()
+        prob = torch.rand(B, C, S // 16, S // 16, generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3).contiguous().cuda()
+        return img, prob
+
+    cases = [scene(3, 2, 64, 1), scene(2, 3, 64, 2), scene(1, 1, 96, 3), scene(4, 2, 64, 4)]
+    monkeypatch.setenv("SIMSEG_CRF_SPATIAL_CACHE", "0")
+    ops._CRF_SPATIAL.clear()
+    want = [ops.dense_crf(img, prob, want_q=True) for img, prob in cases]
+    monkeypatch.setenv("SIMSEG_CRF_SPATIAL_CACHE", "1")
+    ops._CRF_SPATIAL.clear()
+    calls = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(a[-2]) if name == "simseg_dense_crf" else None, real(name, *a))[1])
+    got = [ops.dense_crf(img, prob, want_q=True) for img, prob in cases]
+    torch.cuda.synchronize()
+    # the first call builds, the second (same 64 x 64) reuses; 96 x 96 needs a larger workspace -> fresh; back to 64 x 64 on the NEW workspace: rebuilt
+    assert calls[:2] == [0, 1] and calls[2] == 0, calls
+    for (m0, q0), (m1, q1) in zip(want, got):
+        assert torch.equal(m0, m1) and torch.equal(q0, q1)
+    again = ops.dense_crf(*cases[3], want_q=True)          # same size as the previous call: reused, same bits
+    assert calls[-1] == 1 and torch.equal(again[0], want[3][0]) and torch.equal(again[1], want[3][1])
