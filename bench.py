@@ -656,8 +656,12 @@ def main():
             out["caption_lengths"] = b["caption_lengths"]
         return out
 
+    ZERO_COPY = os.environ.get("SIMSEG_BENCH_SYNC_ZERO_COPY", "0") != "0"      # (measured 0.7 ms SLOWER than the bucket copies: profiles/r4_gradsync_events_ab.txt)
+
     def step():
         opt.zero_grad(set_to_none=(world == 1 or sync is not None))     # under DDP the grads are views into the all-reduce buckets
+        if sync is not None and ZERO_COPY:
+            sync.begin()                                                 # the large weight gradients are written straight into the exchange buffer
         loss_dict, _, _ = net(next_batch())
         loss_dict["nce_loss"].backward()
         if sync is not None:
@@ -862,6 +866,8 @@ def main():
                                            else "derived from the device mask (one host read per step)"),
                        "gradient_sync": ((f"simseg_amd.parallel.GradSync ({dp})" + (" [forced on one rank: no collective]" if world == 1 else "")) if sync is not None
                                          else ("none" if world == 1 else "torch DDP")),
+                       "gradient_sync_detail": ({"zero_copy_weight_gradients": ZERO_COPY, "gradients_copied_per_step": sync.copied_last,
+                                                 "events_per_step": sync.events_last, "buckets": len(sync.buckets)} if sync is not None else None),
                        "tower_streams": 2 if two_streams else 1,
                        "persistent_gemm_reserved_cus": int(os.environ.get("SIMSEG_GEMM_PP2_RESERVE", "0")),
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",

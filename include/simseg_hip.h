@@ -153,6 +153,19 @@ int simseg_attention_bwd_rows(const void* qkv, const int32_t* row_start, const v
                               float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H, float scale, uint64_t drop_seed,
                               float drop_p, void* stream);
 
+/* The same attention on PLANE-MAJOR projection operands (round 4; 16-bit, T <= 256): qkv / dqkv are [3*H][plane_rows][64] - plane
+ * which*H + h holds the 64 channels of head h of q (which = 0), k (1) or v (2) of every token row, i.e. the packed projection
+ * [rows,3,H,64] with the (3,H) axes moved in front of the rows.  It is what simseg_gemm writes with c_planes = plane_rows and reads with
+ * a_planes (the A operand's K-tiles are the planes), so the layout never leaves the three kernels; a head's operand rows are one
+ * contiguous run instead of T cache lines 6*H*64 bytes apart.  Sequence b = rows [b*T, (b+1)*T) when row_start is NULL (timm
+ * Attention.forward, vit_builder.py:18), else [row_start[b], row_start[b+1]) as in simseg_attention_fwd_rows (HF BertSelfAttention,
+ * huggingface_builder.py:16-17).  out / dout [rows,H*64], lse [B,H,T], workspace / dqkv_colsum as in simseg_attention_bwd. */
+int simseg_attention_fwd_planes(const void* qkv, int64_t plane_rows, const int32_t* row_start, void* out, float* lse, int64_t B, int64_t T,
+                                int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream);
+int simseg_attention_bwd_planes(const void* qkv, int64_t plane_rows, const int32_t* row_start, const void* out, const void* dout,
+                                const float* lse, float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H,
+                                float scale, uint64_t drop_seed, float drop_p, void* stream);
+
 /* Prompt ensemble of the zero-shot classifier: out[s,:] = normalize(mean over the P prompt embeddings x[s,:,:]).
  * tools/seg_evaluation.py:71-73 (class_embeddings.mean(dim=0); /= norm()). */
 int simseg_segment_mean_l2norm(const float* x, float* out, int64_t S, int64_t P, int64_t D, void* stream);

@@ -32,6 +32,9 @@ struct AttnParams {
     float* colsum_ws;   // one-kernel backward: [B][3*H*64] per-sequence column sums of dqkv (the qkv bias gradient before the fold over B), or null
     const int* row_start;   // resident forward / one-kernel backward: ragged batch stored WITHOUT its padding - sequence b occupies rows
                             // [row_start[b], row_start[b+1]) of qkv / out / dout / dqkv, every stored token is real; null = dense [B, T] rows
+    long rs, ps;        // resident forward / one-kernel backward: element strides of qkv / dqkv - row r of plane (which * H + h), which = 0 q, 1 k, 2 v,
+                        // starts at plane * ps + r * rs.  Packed projection rows [rows, 3, H, 64]: rs = 3 * H * 64, ps = 64; plane-major
+                        // [3 * H][rows][64] (a head's operand rows are ONE contiguous run): rs = 64, ps = rows * 64
     int pf_stride;      // one-kernel backward: > 0 = touch the operands of head blockIdx.x + pf_stride (the head that takes this CU's place in the
                         // next round) during the tile loop, so that its copies find them in this XCD's L2; 0 = off
 };
@@ -961,10 +964,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int Tf = p.T, T = (MASK || p.row_start) ? attn_teff(p, b) : p.T;     // Tf: the dense row count per sequence; T: the rows this block works on
     if (T <= 0) return;                                        // (an empty sequence of a ragged batch; uniform per block)
     const long row0 = p.row_start ? (long)p.row_start[b] : (long)b * Tf;      // first row of this sequence in qkv / out
-    const long RS = 3L * p.H * 64;
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * 64;
+    const long RS = p.rs;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * p.ps;
     const int nthr = blockDim.x, nw = nthr >> 6;
-    const int HD = p.H * 64;
+    const long HD = p.H * p.ps;                                        // from a head's q plane to its k plane
     const int nt = (T + KT - 1) / KT, q32 = (T + 31) / 32;
     const int rows8 = res_rows8(T), np = rows8 >> 3;                  // 1-KiB pieces per matrix
     char* ldsK = lds;
@@ -2076,9 +2079,9 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         return;
     }
     if (p.trace && tid == 0) p.trace[(long)bh_ * 4] = wall_clock64();
-    const long RS = 3L * p.H * 64, OS = (long)p.H * 64;
+    const long RS = p.rs, OS = (long)p.H * 64, HP = p.H * p.ps;               // HP: from a head's q plane to its k plane, k to v
     const long row0 = p.row_start ? (long)p.row_start[b] : (long)b * Tf;      // first row of this sequence in qkv / out / dout / dqkv
-    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + row0 * RS + h * p.ps;
     const bf16_t* gbase = static_cast<const bf16_t*>(p.dout) + row0 * OS + h * 64;
     const bf16_t* obase = static_cast<const bf16_t*>(p.out) + row0 * OS + h * 64;
     const int q32 = (T + 31) / 32, rows32 = q32 * 32;
@@ -2091,7 +2094,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     const bool active = wave < q32;                   // (a block is launched with one wave per tile of the FULL length)
     res_copy_rows(base, RS, T, rows32, ldsQ, wave, nw, lane);
     res_copy_rows(gbase, OS, T, rows32, ldsG, wave, nw, lane);
-    res_copy_rows(base + p.H * 64, RS, T, rows32, ldsK, wave, nw, lane);
+    res_copy_rows(base + HP, RS, T, rows32, ldsK, wave, nw, lane);
     // every global request of the head goes out before anything waits: the value loads below are consumed after the copies' wait
     // (an LDS store of a loaded value right here would put a full s_waitcnt in front of the remaining requests: the resident passes
     // above pay two to three memory round trips that way, most of their 7.6 us 'waiting for copies')
@@ -2119,7 +2122,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         union { u32x4 v; bf16x8 hh; } uv;          // (keys >= T: row T-1, finite; their probabilities are exactly 0)
-        uv.v = *reinterpret_cast<const u32x4*>(base + (long)min(key, T - 1) * RS + 2 * p.H * 64 + (2 * kk + h2) * 8);
+        uv.v = *reinterpret_cast<const u32x4*>(base + (long)min(key, T - 1) * RS + 2 * HP + (2 * kk + h2) * 8);
         vr[kk] = uv.hh;
     }
     long mk_ = 1;                // the last request: a wait the compiler attaches to this (uniform) branch coincides with the one below
@@ -2168,7 +2171,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         const int nh_ = bh_ + p.pf_stride;
         const int nb_ = nh_ / p.H, nhh_ = nh_ % p.H;
         const long nr_ = p.row_start ? (long)p.row_start[nb_] : (long)nb_ * Tf;
-        const char* qb_ = reinterpret_cast<const char*>(p.qkv) + (nr_ * RS + nhh_ * 64) * 2;
+        const char* qb_ = reinterpret_cast<const char*>(p.qkv) + (nr_ * RS + nhh_ * p.ps) * 2;
         const char* gb_ = reinterpret_cast<const char*>(p.dout) + (nr_ * OS + nhh_ * 64) * 2;
         const char* ob_ = reinterpret_cast<const char*>(p.out) + (nr_ * OS + nhh_ * 64) * 2;
         // (rows32 comes out of shuffles / LDS in attn_teff: uniform, but not provably so - the M0 operand must be scalar)
@@ -2179,7 +2182,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
         for (int k = wave; k < nparts_ * groups_; k += nw) {
             const int part = k / groups_;
             const int r = min((k - part * groups_) * 64 + lane, Tf - 1);
-            const char* sb_ = part < 3 ? qb_ + (long)part * (p.H * 128) : (part == 3 ? gb_ : ob_);
+            const char* sb_ = part < 3 ? qb_ + (long)part * (HP * 2) : (part == 3 ? gb_ : ob_);
             const unsigned voff = (unsigned)((long)r * (part < 3 ? RS : OS) * 2);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sb_), "s"(pad_) : "memory");
         }
@@ -2310,7 +2313,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
     if (active) {
         constexpr int OP = 144;                       // bytes per staged row (128 + 16: 16-byte aligned rows)
         char* ob = stage + wave * (2 * ONE_ST);       // 32 x 144 = 4 608 B
-        bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + row0 * RS + h * 64 + (long)(wave * 32) * RS;
+        bf16_t* dbase = static_cast<bf16_t*>(p.dqkv) + row0 * RS + h * p.ps + (long)(wave * 32) * RS;
         float* cpart = reinterpret_cast<float*>(ldsQ);                 // [wave][3][64] column sums (the operand images are free by now)
         auto put = [&](const f32x16 (&acc)[2], int sel, float mul) {
 #pragma unroll
@@ -2328,7 +2331,7 @@ __global__ __launch_bounds__(512) void attn_bwd_one_kernel(AttnParams p) {
             for (int i = 0; i < 4; ++i) {
                 const int row = (lane >> 3) + 8 * i;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * OP + (lane & 7) * 16);
-                if (wave * 32 + row < T) *reinterpret_cast<u32x4*>(dbase + (long)row * RS + sel * p.H * 64 + (lane & 7) * 8) = v;
+                if (wave * 32 + row < T) *reinterpret_cast<u32x4*>(dbase + (long)row * RS + sel * HP + (lane & 7) * 8) = v;
             }
             if (p.colsum_ws) {       // column sums of the tile's (rounded, as stored) valid rows: lane = 4 columns x every 4th row, 8-byte reads
                 const int nrow = min(32, T - wave * 32), cg = lane & 15, rg = lane >> 4;
@@ -2427,6 +2430,7 @@ int fill_params(AttnParams& p, const void* qkv, const int64_t* mask, int64_t B, 
     memset(&p, 0, sizeof(p));
     p.qkv = qkv; p.mask = (const long*)mask; p.B = (int)B; p.T = (int)T; p.H = (int)H;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.rs = 3L * H * 64; p.ps = 64;          // the packed projection rows; the *_planes entry points overwrite these
     p.dbg = g_attn_variant;
     p.trace = g_attn_trace;
     p.drop_seed = seed;
@@ -2637,6 +2641,45 @@ extern "C" int simseg_attention_bwd_rows(const void* qkv, const int32_t* row_sta
     p.colsum_ws = dqkv_colsum ? workspace + B * H * T : nullptr;
     if (int rc = p.drop_thresh ? launch_bwd_one<true>(p, s) : launch_bwd_one<false>(p, s)) return rc;
     SS_LAUNCH_CHECK("attention_bwd_rows");
+    if (dqkv_colsum) return simseg_colsum_accum(p.colsum_ws, 0, dqkv_colsum, B, 3 * H * 64, 3 * H * 64, stream);
+    return 0;
+}
+
+// ---- plane-major projection operands (round 4) -----------------------------------------------------------------------------------
+// qkv / dqkv as [3 * H][plane_rows][64]: plane which * H + h holds the 64 channels of head h of q (which = 0), k (1) or v (2) for every
+// token row - what the qkv GEMM's plane-wise epilogue writes and what the dgrad / wgrad GEMMs read with a K-tile stride.  A head's operand
+// rows are then ONE contiguous run (25 KB at T = 197) instead of T lines 4.6 KB apart.  Sequence b = rows [b * T, (b + 1) * T) when
+// row_start is null (dense batch, no key mask), else rows [row_start[b], row_start[b + 1]) as in the *_rows entry points.  T <= 256, 16-bit only.
+extern "C" int simseg_attention_fwd_planes(const void* qkv, int64_t plane_rows, const int32_t* row_start, void* out, float* lse, int64_t B, int64_t T,
+                                           int64_t H, float scale, uint64_t drop_seed, float drop_p, void* stream) {
+    SS_HALF_FWD(simseg_attention_fwd_planes, qkv, plane_rows, row_start, out, lse, B, T, H, scale, drop_seed, drop_p, stream);
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out, "attention_fwd_planes: null pointer");
+    SS_CHECK(T <= RES_MAXT, "attention_fwd_planes: sequences of at most %d tokens (got %lld)", RES_MAXT, (long long)T);
+    SS_CHECK(plane_rows >= (row_start ? 1 : B * T), "attention_fwd_planes: plane_rows %lld is smaller than the batch", (long long)plane_rows);
+    p.out = out; p.lse = lse; p.row_start = row_start; p.rs = 64; p.ps = plane_rows * 64;
+    int rc = p.drop_thresh ? launch_fwd_res<true, true>(p, (hipStream_t)stream) : launch_fwd_res<false, false>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    SS_LAUNCH_CHECK("attention_fwd_planes");
+    return 0;
+}
+
+extern "C" int simseg_attention_bwd_planes(const void* qkv, int64_t plane_rows, const int32_t* row_start, const void* out, const void* dout,
+                                           const float* lse, float* workspace, void* dqkv, float* dqkv_colsum, int64_t B, int64_t T, int64_t H,
+                                           float scale, uint64_t drop_seed, float drop_p, void* stream) {
+    SS_HALF_FWD(simseg_attention_bwd_planes, qkv, plane_rows, row_start, out, dout, lse, workspace, dqkv, dqkv_colsum, B, T, H, scale, drop_seed, drop_p, stream);
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, scale, drop_seed, drop_p)) return rc;
+    SS_CHECK(out && dout && lse && workspace && dqkv, "attention_bwd_planes: null pointer");
+    SS_CHECK(T <= ONE_MAXT, "attention_bwd_planes: sequences of at most %d tokens (got %lld)", ONE_MAXT, (long long)T);
+    SS_CHECK(plane_rows >= (row_start ? 1 : B * T), "attention_bwd_planes: plane_rows %lld is smaller than the batch", (long long)plane_rows);
+    p.out = const_cast<void*>(out); p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = workspace; p.dqkv = dqkv; p.row_start = row_start;
+    p.rs = 64; p.ps = plane_rows * 64;
+    hipStream_t s = (hipStream_t)stream;
+    p.colsum_ws = dqkv_colsum ? workspace + B * H * T : nullptr;
+    if (int rc = p.drop_thresh ? launch_bwd_one<true>(p, s) : launch_bwd_one<false>(p, s)) return rc;
+    SS_LAUNCH_CHECK("attention_bwd_planes");
     if (dqkv_colsum) return simseg_colsum_accum(p.colsum_ws, 0, dqkv_colsum, B, 3 * H * 64, 3 * H * 64, stream);
     return 0;
 }

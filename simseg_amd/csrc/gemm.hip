@@ -916,7 +916,7 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const u32x4*>(Ab + (i * 2 + (q >> 1)) * 1024 + (q & 1) * 8);
         };
         load_blk(0, ax[0]);
-        float sL = 0.f, sR = 0.f;
+        f32x2 sLR = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < 3) load_blk(i + 1, ax[(i + 1) & 1]);
@@ -926,15 +926,17 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
                 union { u32x4 v; bf16_t h[8]; } gl, gr;
                 gl.v = ax[i & 1][q]; gr.v = ax[i & 1][2 + q];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    l[8 * q + e] = (acc[i][0][8 * q + e] * p.alpha + bL) * (float)gl.h[e];
-                    r[8 * q + e] = (acc[i][1][8 * q + e] * p.alpha + bR) * (float)gr.h[e];
-                    sL += l[8 * q + e]; sR += r[8 * q + e];
+                for (int e = 0; e < 8; ++e) {        // (left, right) as one pair: packed fp32 arithmetic
+                    const f32x2 v = __builtin_elementwise_fma((f32x2){acc[i][0][8 * q + e], acc[i][1][8 * q + e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR}) *
+                                    (f32x2){(float)gl.h[e], (float)gr.h[e]};
+                    l[8 * q + e] = v.x; r[8 * q + e] = v.y;
+                    sLR += v;
                 }
             }
             emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
         }
         if (p.colsum) {
+            float sL = sLR.x, sR = sLR.y;
             sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
             if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
         }
@@ -945,18 +947,20 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             f32x16 l, r;
             union { u32x4 v[2]; bf16_t h[16]; } dl, dr;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float d0, d1;
-                l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
-                r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
-                dl.h[e] = (bf16_t)d0; dr.h[e] = (bf16_t)d1;
+            for (int e = 0; e < 16; ++e) {           // the left / right element as one pair: packed fp32 arithmetic (common.h)
+                f32x2 d;
+                f32x2 y = __builtin_elementwise_fma((f32x2){acc[i][0][e], acc[i][1][e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR});
+                if (p.stagger != 1002) y = gelu_poly_grad2(y, d); else d = y;
+                l[e] = y.x; r[e] = y.y;
+                dl.h[e] = (bf16_t)d.x; dr.h[e] = (bf16_t)d.y;
             }
+            if (p.stagger != 1001)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 *reinterpret_cast<u32x4*>(Bb + (i * 2) * 1024 + q * 8) = dl.v[q];
                 *reinterpret_cast<u32x4*>(Bb + (i * 2 + 1) * 1024 + q * 8) = dr.v[q];
             }
-            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+            if (p.stagger != 1003) emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
         }
     } else if (EK == 1 && p.act == 4) {
         // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
@@ -1056,10 +1060,10 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             f32x16 l, r, dl, dr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float d0, d1;
-                l[e] = gelu_poly_grad(acc[i][0][e] * p.alpha + bL, d0);
-                r[e] = gelu_poly_grad(acc[i][1][e] * p.alpha + bR, d1);
-                dl[e] = d0; dr[e] = d1;
+                f32x2 d;
+                const f32x2 y = gelu_poly_grad2(__builtin_elementwise_fma((f32x2){acc[i][0][e], acc[i][1][e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR}), d);
+                l[e] = y.x; r[e] = y.y;
+                dl[e] = d.x; dr[e] = d.y;
             }
             const int row0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32;
             emit(l, r, Cb, row0);
@@ -1075,8 +1079,8 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
         for (int e = 0; e < 16; ++e) {
             float vl = l[e] * p.alpha + bL, vr = r[e] * p.alpha + bR;
             dl[e] = vl; dr[e] = vr;                          // act 1: the saved pre-activation
-            if (p.act == 1) { vl = gelu_poly(vl); vr = gelu_poly(vr); }
-            else if (p.act == 3) { float d0, d1; vl = gelu_poly_grad(vl, d0); vr = gelu_poly_grad(vr, d1); dl[e] = d0; dr[e] = d1; }
+            if (p.act == 1) { const f32x2 y = gelu_poly2((f32x2){vl, vr}); vl = y.x; vr = y.y; }
+            else if (p.act == 3) { f32x2 d; const f32x2 y = gelu_poly_grad2((f32x2){vl, vr}, d); vl = y.x; vr = y.y; dl[e] = d.x; dr[e] = d.y; }
             l[e] = vl; r[e] = vr;
         }
         emit(l, r, Cb, row0);

@@ -256,6 +256,36 @@ def attention_bwd_rows(qkv, out, dout, lse, heads, row_start, max_len, scale=0.1
     return dqkv
 
 
+def attention_fwd_planes(qkvp, heads, B, T, row_start=None, scale=0.125, save_lse=False, drop_seed=0, drop_p=0.0, n_real=None):
+    """Plane-major operands: qkvp [3*H, rows, 64] (16-bit) -> ctx [rows, H*64], lse [B,H,T].  Sequence b = rows [b*T, (b+1)*T) (row_start None)
+    or [row_start[b], row_start[b+1]) (int32 [B+1]); rows outside every sequence (behind n_real) are zeros."""
+    require_gpu(qkvp)
+    P3, rows, d = qkvp.shape
+    if qkvp.dtype not in HALF_TYPES or P3 != 3 * heads or d != 64 or not qkvp.is_contiguous():
+        raise ValueError("attention_fwd_planes: contiguous 16-bit [3*H, rows, 64]")
+    out = torch.empty(rows, heads * 64, device=qkvp.device, dtype=qkvp.dtype)
+    if n_real is not None and n_real < rows:
+        out[n_real:].zero_()
+    lse = torch.empty(B, heads, T, device=qkvp.device, dtype=torch.float32) if save_lse else None
+    _push_variant("attention")
+    call("simseg_attention_fwd_planes", ptr(qkvp), rows, ptr(_c(row_start)), ptr(out), ptr(lse), B, int(T), heads, float(scale), int(drop_seed),
+         float(drop_p), stream())
+    return out, lse
+
+
+def attention_bwd_planes(qkvp, out, dout, lse, heads, B, T, row_start=None, scale=0.125, drop_seed=0, drop_p=0.0, colsum=None, n_real=None):
+    """dqkv [3*H, rows, 64] for attention_fwd_planes (rows behind n_real zeroed); colsum (optional fp32 [3*H*64]) += its column sums."""
+    P3, rows, d = qkvp.shape
+    dqkv = torch.empty_like(qkvp)
+    if n_real is not None and n_real < rows:
+        dqkv[:, n_real:].zero_()
+    ws = torch.empty(raw("simseg_attention_bwd_workspace_bytes", B, int(T), heads) // 4, device=qkvp.device, dtype=torch.float32)
+    _push_variant("attention")
+    call("simseg_attention_bwd_planes", ptr(qkvp), rows, ptr(_c(row_start)), ptr(_c(out)), ptr(_c(dout)), ptr(lse), ptr(ws), ptr(dqkv), ptr(colsum),
+         B, int(T), heads, float(scale), int(drop_seed), float(drop_p), stream())
+    return dqkv
+
+
 def segment_mean_l2norm(x):
     """[S,P,D] fp32 -> [S,D]: unit-norm mean over P."""
     require_gpu(x)

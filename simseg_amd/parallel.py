@@ -16,10 +16,20 @@ reference's all-reduce semantics (mean over ranks, simseg/core/hooks/dist.py:48-
 form: one flat all-reduce after the backward.
 
     sync = GradSync(model.parameters())
-    loss.backward(); sync.finish(); optimizer.step()
+    sync.begin(); loss = model(batch); loss.backward(); sync.finish(); optimizer.step()
+
+`begin()` (optional, before the forward pass) zero-fills the flat buffer and arms the ZERO-COPY path: the towers' backward functions
+(simseg_amd/towers.py `_grad_target`) then accumulate the large weight gradients - the split-K GEMMs add into a zero-filled output
+anyway - straight into their views of the flat buffer, autograd adopts those views as `.grad`, and the bucket hand-over has nothing to
+copy for them (the copies of a 64 MiB bucket were 14 x ~140 us of a 512-pair step, profiles/r4_gradsync_zero_copy.txt).  Without
+`begin()` every gradient is copied into its view as before.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_EVENTS = os.environ.get("SIMSEG_GRADSYNC_EVENTS", "needed")      # "all": an event per parameter, as before round 4 (A/B runs)
 
 
 class GradSync:
@@ -51,15 +61,88 @@ class GradSync:
         self._on = False
         self._comm = None
         self._handles = []
+        self._armed = False
+        self._split_done = False
+        # Which gradients need an event of their own.  A bucket is handed over on the stream that produced its LAST gradient; members
+        # produced on that same stream are ordered by the stream itself, and with the towers on two streams that is all but a handful per
+        # step (the buckets at a tower boundary).  An event record per parameter - ~400 barrier packets with release fences in the two compute
+        # streams - measured 2.2 ms of a 86.5 ms step (profiles/r4_gradsync_events_ab.txt), so only the members that were produced on ANOTHER
+        # stream than their bucket's hand-over in the previous step record one (first step: all); a member that turns out to need one
+        # without having it gets a late event on its stream at the hand-over (correct; waits for more than it has to, once).
+        self._need_ev = [True] * len(self.params)
+        self.events_last = None
+        self._nev = 0
+        self.copied_last = None               # gradients that had to be copied into their views in the last step (tests / bench)
+        self._copied = 0
+        for i, p in enumerate(self.params):
+            p._simseg_grad_target = self._make_target(i)
         if overlap:
             for i, p in enumerate(self.params):
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self._reset()
 
+    def _make_target(self, i):
+        def target():
+            """A FRESH view of parameter i's slice of the flat buffer (autograd adopts a gradient tensor nobody else references), or None
+            when this step was not armed with begin()."""
+            if not self._armed:
+                return None
+            v = self.views[i]
+            return v.view(v.shape)
+        return target
+
+    @torch.no_grad()
+    def begin(self):
+        """Before the forward pass of a step: zero the flat buffer (on the current stream - the tower streams fork from it later) and let the
+        backward functions write the large weight gradients straight into it."""
+        self.flat.zero_()
+        self._armed = True
+        self._copied = 0
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        for p in self.params:
+            if hasattr(p, "_simseg_grad_target"):
+                del p._simseg_grad_target
+
+    def _split_by_stream(self):
+        """After the first step: a bucket whose gradients were produced on more than one stream (the towers run on two; a bucket at a tower
+        boundary holds the last layers of one and the first of the other) is cut into its runs of same-stream members.  Its hand-over
+        otherwise makes the stream that completes it wait for the OTHER tower's stream - the two towers serialise there, 1.5-2 ms of an
+        86.5 ms step with the default 64 MiB buckets (profiles/r4_gradsync_events_ab.txt) - and with stream-pure buckets no hand-over waits for
+        anything but its own stream.  The flat layout does not change: a run is a contiguous sub-range."""
+        self._split_done = True
+        out = []
+        for bk in self.buckets:
+            lo, run = bk["lo"], None
+            for i in bk["members"]:
+                st = self._prod[i]
+                if run is None or (st is not None and run["st"] is not None and st != run["st"]):
+                    run = {"lo": lo, "n": 0, "members": [], "st": st}
+                    out.append(run)
+                elif run["st"] is None:
+                    run["st"] = st
+                run["members"].append(i); run["n"] += self.params[i].numel()
+                lo += self.params[i].numel()
+        if self._world() > 1:       # every rank must cut the same way (the collectives are per bucket): same code, same streams - checked once
+            sig = torch.tensor([len(out), sum((k + 1) * r["lo"] for k, r in enumerate(out)) % (1 << 40)], device=self.flat.device, dtype=torch.int64)
+            lo_, hi_ = sig.clone(), sig.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo_, hi_):
+                return                  # (ranks disagree: keep the common, uncut buckets)
+        if len(out) != len(self.buckets):
+            self.buckets = [{"lo": r["lo"], "n": r["n"], "members": r["members"]} for r in out]
+            self._bucket_of = {i: b for b, bk in enumerate(self.buckets) for i in bk["members"]}
+
     def _reset(self):
         self._pending = [len(bk["members"]) for bk in self.buckets]
         self._events = [[] for _ in self.buckets]
         self._works = []
+        self._prod = [None] * len(self.params)      # the stream each gradient was produced on in this step
+        self._has_ev = [False] * len(self.params)
 
     def _world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -89,11 +172,23 @@ class GradSync:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad); dst.append(v)
+        self._copied += len(dst)
         if self.flat.is_cuda:
             cur = torch.cuda.current_stream()
             for ev, st in self._events[b]:
                 if st != cur:
                     cur.wait_event(ev)
+            late = []
+            for i in self.buckets[b]["members"]:
+                st = self._prod[i]
+                self._need_ev[i] = st is not None and st != cur
+                if self._need_ev[i] and not self._has_ev[i] and st not in late:
+                    late.append(st)
+            for st in late:                       # (a member the previous step's pattern did not predict)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
+                self._nev += 1
         if dst:
             torch._foreach_copy_(dst, src)
         for i in self.buckets[b]["members"]:
@@ -113,9 +208,14 @@ class GradSync:
                 raise RuntimeError("GradSync(overlap=True): a parameter's gradient arrived again after its bucket was reduced - exactly one "
                                    "backward per finish(); for gradient accumulation use GradSync(overlap=False) or accumulate inside one backward")
             if self.flat.is_cuda:
-                ev = torch.cuda.Event()
-                ev.record()                       # on the stream this gradient was produced on (main or the text tower's)
-                self._events[b].append((ev, torch.cuda.current_stream()))
+                st = torch.cuda.current_stream()  # the stream this gradient was produced on (main or the text tower's)
+                self._prod[i] = st
+                if self._need_ev[i] or _EVENTS == "all":
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._events[b].append((ev, st))
+                    self._has_ev[i] = True
+                    self._nev += 1
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._gather_bucket(b)
@@ -134,6 +234,7 @@ class GradSync:
                     v.zero_()
                 elif p.grad.data_ptr() != v.data_ptr():
                     src.append(p.grad); dst.append(v)
+            self._copied += len(dst)
             if dst:
                 torch._foreach_copy_(dst, src)
             if world > 1:
@@ -155,6 +256,11 @@ class GradSync:
             self.flat.div_(world)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._armed = False
+        self.copied_last, self._copied = self._copied, 0
+        self.events_last, self._nev = self._nev, 0
+        if self.overlap and self.flat.is_cuda and not self._split_done:
+            self._split_by_stream()
         self._reset()
 
     __call__ = finish

@@ -181,6 +181,21 @@ def _zeros(device, *shapes):
     return [buf[a:a + n].view(sh) for a, n, sh in zip(offs, sizes, shapes)]
 
 
+def _grad_target(p):
+    """Where a data-parallel gradient exchange wants parameter p's gradient written: a fresh, zero-filled view of its flat buffer
+    (simseg_amd/parallel.py GradSync.begin()) - the split-K weight-gradient GEMMs accumulate into a zeroed output anyway, and autograd adopts
+    the returned view as `.grad`, so the exchange has nothing to copy - or None (no exchange / not armed: a private zero buffer)."""
+    f = getattr(p, "_simseg_grad_target", None)
+    return f() if f is not None else None
+
+
+def _zeros_or(device, targets, *shapes):
+    """_zeros(), except that entry i is `targets[i]` where that is a tensor of the right shape."""
+    use = [t is not None and tuple(t.shape) == tuple(torch.Size(sh if not isinstance(sh, int) else (sh,))) for t, sh in zip(targets, shapes)]
+    rest = iter(_zeros(device, *[sh for sh, u in zip(shapes, use) if not u]))
+    return [t if u else next(rest) for t, u in zip(targets, use)]
+
+
 # Weight gradients on their own stream (opt-in experiment, SIMSEG_AMD_WGRAD_STREAM=1): a block's four weight-gradient GEMMs depend only on
 # tensors its backward already has and nothing reads their results before the optimizer, so they can run beside the data-gradient chain
 # (dgrad -> LayerNorm backward -> attention backward ...) instead of inside it.  One extra stream per stream the backward runs on (the two
@@ -436,6 +451,7 @@ class ViTBlockFn(_GradAwareFn):
         act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=(5 if blk else 3) if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
         y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
         ctx.adt, ctx.heads, ctx.dims, ctx.blk = adt, heads, (B, T, D), blk
+        ctx.wparams = (f2w, f1w, pw, qw)                                  # (the parameter objects: _grad_target in the backward)
         if save:
             ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_,
                                   n1w.detach(), n2w.detach())
@@ -456,8 +472,10 @@ class ViTBlockFn(_GradAwareFn):
         else:
             dy16 = _act_grad(dy, adt)
             df2b = _bgrad(dy16) if need[14] else None
-        (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros(
-            dy.device, (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
+        tg = [_grad_target(w) if nd else None for w, nd in zip(ctx.wparams, (need[13], need[11], need[7], need[5]))]
+        (df1b, df2w_z, df1w_z, dn2w, dn2b, dpb, dpw_z, dqw_z, dqb_z, dn1w, dn1b, dsum) = _zeros_or(
+            dy.device, (None, tg[0], tg[1], None, None, None, tg[2], tg[3], None, None, None, None),
+            (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
         dpre = _dgrad(dy16, f2w_, act=6 if ctx.blk else 4, aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
@@ -508,6 +526,7 @@ class BertEmbedFn(Function):
             ops.dropout_apply_(y, seed, drop_p)
         ctx.drop = (drop_p, seed)
         ctx.shapes = (word.shape, pos.shape, typ.shape)
+        ctx.wparams = (word,)
         ctx.save_for_backward(ids, mask, s, mean, rstd, lnw.detach())
         return y
 
@@ -524,7 +543,9 @@ class BertEmbedFn(Function):
         wshape, pshape, tshape = ctx.shapes
         dword = dpos = dtyp = None
         if ctx.needs_input_grad[2]:
-            dword = torch.zeros(wshape, device=dy.device, dtype=F32)
+            dword = _grad_target(ctx.wparams[0])                      # (scatter-add into zeros: the exchange buffer's view will do)
+            if dword is None or dword.shape != wshape:
+                dword = torch.zeros(wshape, device=dy.device, dtype=F32)
             ops.bert_embed_bwd(ids, mask, ds, dword)
         if ctx.needs_input_grad[3]:
             dpos = torch.zeros(pshape, device=dy.device, dtype=F32)
@@ -705,6 +726,7 @@ class BertLayerFn(_GradAwareFn):
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
         ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv, ctx.blk = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv, blk
+        ctx.wparams = (o2w, iw, ow)                                       # (the parameter objects: _grad_target in the backward)
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
                                   law.detach(), low.detach(), attd if (packed and not rows) else None, idx, inv, cu if rows else None)
@@ -721,8 +743,10 @@ class BertLayerFn(_GradAwareFn):
         need = ctx.needs_input_grad
         dy = dy.contiguous().view(-1, D)
         I = pre.shape[1]
-        (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros(
-            dy.device, (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
+        tg = [_grad_target(w) if nd else None for w, nd in zip(ctx.wparams, (need[18], need[16], need[12]))]
+        (dlow, dlob, do2b, dib, do2w_z, diw_z, dlaw, dlab, dob, dow_z, dwqkv_z, dbqkv_z) = _zeros_or(
+            dy.device, (None, None, None, None, tg[0], tg[1], None, None, None, tg[2], None, None),
+            (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
         ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt != F32 else dy, dy32=dy if adt != F32 else None,
                              dxsum=do2b, drop=(p, seed + 2))
         dpre = _dgrad(d2, o2w_, act=6 if ctx.blk else 4, aux=pre, colsum=dib)

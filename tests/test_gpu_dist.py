@@ -256,6 +256,17 @@ def _worker_sync_and_retrieval(rank, world, port, backend, q):
         sync3.finish()
         torch.cuda.synchronize()
         res["grads_default_buckets"] = {n: p.grad.detach().float().cpu().numpy() for n, p in m3.named_parameters() if p.grad is not None}
+        # ... and armed with begin(): the blocks' weight-gradient GEMMs and the word-embedding scatter accumulate straight into the exchange
+        # buffer (towers._grad_target); those gradients are adopted by autograd and never copied
+        copied_plain = sync3.copied_last
+        for p in m3.parameters():
+            p.grad = None
+        sync3.begin()
+        m3(batch)[0]["nce_loss"].backward()
+        sync3.finish()
+        torch.cuda.synchronize()
+        res["grads_zero_copy"] = ({n: p.grad.detach().float().cpu().numpy() for n, p in m3.named_parameters() if p.grad is not None},
+                                  copied_plain, sync3.copied_last, len(sync3.params))
         os.environ.pop("SIMSEG_AMD_TWO_STREAMS", None)
 
         # (b) retrieval: 60 images x 5 captions, rows dealt to the ranks unevenly (rank 0: 170 rows, rank 1: 130)
@@ -302,6 +313,12 @@ def test_gradsync_overlap_equals_ddp_and_sharded_retrieval_equals_single(world):
             # exact-fp32 kernels on both sides; the differences are the order of the two ranks' sum and atomics inside kernels
             np.testing.assert_allclose(got[name], want[name], rtol=0, atol=2e-5 * scale + 1e-9, err_msg=f"rank {r} {name}")
             np.testing.assert_allclose(out[r]["grads_default_buckets"][name], want[name], rtol=0, atol=2e-5 * scale + 1e-9, err_msg=f"rank {r} {name} (64 MiB buckets)")
+        zc, copied_plain, copied_armed, nparams = out[r]["grads_zero_copy"]
+        for name in want:
+            scale = float(np.abs(want[name]).max()) + 1e-12
+            np.testing.assert_allclose(zc[name], want[name], rtol=0, atol=2e-5 * scale + 1e-9, err_msg=f"rank {r} {name} (zero-copy exchange)")
+        # every gradient copied without begin(); armed, the block weight matrices (7 per layer pair) and the word embeddings are not
+        assert copied_plain == nparams and copied_armed < copied_plain - 6, (copied_plain, copied_armed, nparams)
     for name in out[0]["grads"][1]:              # averaged gradients are the same on every rank
         np.testing.assert_array_equal(out[0]["grads"][1][name], out[1]["grads"][1][name])
     assert out[1]["retr_multi"] is None

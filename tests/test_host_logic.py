@@ -362,3 +362,48 @@ def test_ping_pong_gemm_kernels_spill_nothing_outside_the_saved_derivative_epilo
             else:
                 assert spill <= 48 and scratch <= 200, (obj, name, vgpr, spill, scratch)
     assert all(seen[k] > 0 for k in seen), seen
+
+
+def test_gradsync_zero_copy_targets():
+    """GradSync.begin() arms the zero-copy path: a backward function that accumulates its weight gradient into towers._grad_target(param)
+    (a fresh, zero-filled view of the exchange buffer) hands autograd a tensor it ADOPTS as .grad - the bucket hand-over then copies
+    nothing; without begin() the same backward gets no target and every gradient is copied.  Same gradients either way."""
+    import torch
+    from torch.autograd import Function
+    from simseg_amd.parallel import GradSync
+    from simseg_amd.towers import _grad_target, _zeros_or
+
+    class Lin(Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            ctx.save_for_backward(x, w.detach())
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            (dw,) = _zeros_or(x.device, (_grad_target(ctx.w),), tuple(w.shape))
+            dw.addmm_(dy.t(), x)
+            return dy @ w, dw
+
+    torch.manual_seed(0)
+    w1, w2 = torch.nn.Parameter(torch.randn(5, 4)), torch.nn.Parameter(torch.randn(3, 5))
+    b = torch.nn.Parameter(torch.zeros(3))
+    x = torch.randn(7, 4)
+    want = torch.autograd.grad(((x @ w1.t()) @ w2.t() + b).square().sum(), (w1, w2, b))
+    for overlap in (True, False):
+        sync = GradSync([w1, w2, b], overlap=overlap)
+        for armed, copies in ((False, 3), (True, 1), (True, 1), (False, 3)):
+            for p in (w1, w2, b):
+                p.grad = None
+            if armed:
+                sync.begin()
+            (Lin.apply(Lin.apply(x, w1), w2) + b).square().sum().backward()
+            sync.finish()
+            assert sync.copied_last == copies, (overlap, armed, sync.copied_last)
+            for p, v, g in zip(sync.params, sync.views, want):
+                assert p.grad.data_ptr() == v.data_ptr() and torch.allclose(p.grad, g, atol=1e-5)
+        assert _grad_target(w1) is None              # not armed between steps
+        sync.close()
+        assert not hasattr(w1, "_simseg_grad_target")

@@ -69,6 +69,10 @@ def run(kind, M, N, K, iters, out_f32=False, act=0, colsum=False):
             kw.update(act=3, bias=torch.zeros(N, device=dev), aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
         elif act == 4:      # dgrad through fc2 as the training step runs it: times the saved derivative
             kw.update(act=4, aux=torch.randn(M, N, device=dev, generator=g).bfloat16())
+        elif act == 7:      # fc1 forward with GELU' saved as the tile-blocked accumulator image (what the step runs on full tiles)
+            kw.update(act=5, bias=torch.zeros(N, device=dev), aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif act == 8:      # dgrad through fc2 reading that image
+            kw.update(act=6, aux=torch.randn(M, N, device=dev, generator=g).bfloat16())
         elif act == 5:      # proj / fc2 forward: bias + fp32 residual, fp32 output
             kw.update(bias=torch.zeros(N, device=dev), residual=torch.randn(M, N, device=dev, generator=g), out_dtype=torch.float32)
         if colsum:
