@@ -120,6 +120,9 @@ int simseg_debug_attn_trace(void* buf);
  * start, K loop end, block end; HW_ID) - tools/dbg_gemm_trace.py; NULL switches it off. */
 int simseg_debug_gemm_trace(void* buf);
 int simseg_debug_gemm_stagger(int ticks);
+/* debug / experiments (thread-local): > 0 = the split-K weight-gradient GEMMs (transA, fp32 accumulate) use at most this many 256x256
+ * blocks, i.e. CUs, instead of one round of all of them; 0 = default. */
+int simseg_debug_gemm_wgrad_blocks(int blocks);
 
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]

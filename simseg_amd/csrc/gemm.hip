@@ -1660,6 +1660,7 @@ int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
 thread_local int g_gemm_debug_skip_epilogue = 0;
 thread_local unsigned long long* g_gemm_debug_trace = nullptr;
 thread_local int g_gemm_stagger = 0;
+thread_local int g_gemm_wgrad_blocks = 0;      // > 0: the split-K weight gradients use at most this many 256x256 blocks (simseg_debug_gemm_wgrad_blocks)
 thread_local int g_gemm_last_variant = 0;      // 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS, 3 = 256x256 ping-pong
 // variant: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 direct-to-LDS (BK64, 2 stages).  Other points of the design
 // space were measured and dropped (profiles/r1_gemm_variants.txt): 256x256 with a 4-deep BK32 ring, 256x128 at 2 blocks/CU,
@@ -1836,6 +1837,9 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         // runs two rounds, the second 12 % full)
         if ((v == 0 || v == 6 || v == 3) && v != 7 && big_ok && p.accumulate && splitk > 1 && p.M % 256 == 0 && p.N % 256 == 0 && tiles256 <= 128) {
             int sk = 256 / tiles256;
+            static const int env_blocks = getenv("SIMSEG_GEMM_WGRAD_BLOCKS") ? atoi(getenv("SIMSEG_GEMM_WGRAD_BLOCKS")) : 0;      // (process-wide: backward runs on autograd's threads)
+            const int wb = g_gemm_wgrad_blocks > 0 ? g_gemm_wgrad_blocks : env_blocks;
+            if (wb > 0) sk = wb / tiles256 > 0 ? wb / tiles256 : 1;      // (CU-partition experiments)
             if (nk64 / sk < 16 && nk64 >= 64) sk = nk64 / 16;        // short contraction (packed text rows): fewer, 16-deep slices
             if (nk64 / sk >= 16 && tiles256 * sk >= 96 && (v == 3 || v == 0)) {
                 g_gemm_last_variant = 3;
@@ -1934,6 +1938,13 @@ extern "C" int simseg_gemm_last_variant(void) {
 
 // debugging: the ping-pong kernel writes 5 x u64 per block (start / K loop start / K loop end / end wall-clock stamps at 100 MHz, HW_ID)
 extern "C" int simseg_debug_gemm_stagger(int ticks) { g_gemm_stagger = ticks; return 0; }
+extern "C" int simseg_debug_gemm_wgrad_blocks(int blocks) {
+#ifndef SS_HALF
+    simseg_debug_gemm_wgrad_blocks_h16(blocks);
+#endif
+    g_gemm_wgrad_blocks = blocks;
+    return 0;
+}
 extern "C" int simseg_debug_gemm_trace(void* buf) { g_gemm_debug_trace = static_cast<unsigned long long*>(buf); return 0; }
 
 extern "C" int simseg_set_gemm_variant(int v) {

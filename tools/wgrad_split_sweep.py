@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simseg_amd import ops  # noqa: E402
+from simseg_amd.lib import call  # noqa: E402
 from simseg_amd.towers import _splitk  # noqa: E402
 
 MV, MB, MT = 512 * 197, 512 * 77, 22016
@@ -22,6 +23,7 @@ for M, N, K in ((2304, 768, MV), (768, 768, MV), (3072, 768, MV), (768, 3072, MV
     cands = sorted({cur, max(1, 256 // tiles), max(1, 256 // tiles - 1), max(1, 256 // tiles + 1), max(1, 512 // tiles), max(1, 128 // tiles)})
     row = []
     for sk in cands:
+        call("simseg_debug_gemm_wgrad_blocks", tiles * sk)      # (the dispatcher otherwise picks one round of all CUs whatever the caller asks for)
         kw = dict(trans_a=True, trans_b=True, out=out, accumulate=True, splitk=sk)
         for _ in range(3):
             ops.gemm(dy, x, **kw)
