@@ -56,6 +56,17 @@ class CLIPModel(nn.Module):
             return feats[:, 0] if feats.dim() == 3 else feats
         return feats[:, 1:] if feats.dim() == 3 else feats
 
+    def _image_embeddings(self, image):
+        """forward_image_project(forward_image_feature(image)) for the training / embedding path.  With the fused heads the tower's whole
+        output goes to ProjectPoolFn, which leaves the [cls] token out of the pooling itself (skip=1) - no slice copy of the features, no
+        zero-filled scatter of their gradient, no cast (simseg_amd/towers.py ProjectPoolFn).  Same values as the two calls."""
+        if self._fused_heads and self.cfg.model.pool.name != "identity" and os.environ.get("SIMSEG_AMD_FUSED_IMAGE_HEAD", "1") != "0":
+            feats = self.image_encoder(image)
+            if feats.dim() == 3 and feats.is_cuda:
+                return ProjectPoolFn.apply(feats, self.image_projection.linear.weight, self.image_pool.k, None, compute_dtype(), 1)
+            return self.forward_image_project(feats[:, 1:] if feats.dim() == 3 else feats)
+        return self.forward_image_project(self.forward_image_feature(image))
+
     def forward_image_project(self, image_features):
         """projection -> LoDA pool -> L2norm: [B,N,D] -> [B,P] (clip.py:87-93), one fused node."""
         if self._fused_heads and image_features.dim() == 3:
@@ -119,7 +130,7 @@ class CLIPModel(nn.Module):
             side = _side_stream(image.device)
             side.wait_stream(main)
             # (which tower is enqueued first makes no measurable difference: 126.2 vs 126.4 ms/step)
-            img = self.forward_image_project(self.forward_image_feature(image))
+            img = self._image_embeddings(image)
             self._prefetch(img, embeddings)          # the image embeddings travel while the text tower is still computing
             with torch.cuda.stream(side), packed_text(lengths):
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)
@@ -134,7 +145,7 @@ class CLIPModel(nn.Module):
                 if t.is_cuda:
                     t.record_stream(side)
         else:
-            img = self.forward_image_project(self.forward_image_feature(image))
+            img = self._image_embeddings(image)
             self._prefetch(img, embeddings)
             with packed_text(lengths):      # only the masked pooling reads the text tower's output here: padded token rows are not computed
                 txt = self.forward_text_project(self.forward_text_feature(ids, mask), mask)

@@ -359,9 +359,13 @@ class LinearFn(_GradAwareFn):
 
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, adt=None):
         x = x.contiguous()
-        y, _, mean, rstd = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, save_stats=True)
+        # (adt = a 16-bit compute type: the kernel writes a copy of y in it next to the fp32 rows, picked up by the consumer - ProjectPoolFn
+        #  through y._simseg_fwd16 - instead of a cast pass over the features)
+        y, y16, mean, rstd = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, save_stats=True, want_bf16_copy=adt if adt in ops.HALF_TYPES else False)
+        if y16 is not None:
+            y._simseg_fwd16 = (y16, y._version)
         ctx.save_for_backward(x, mean, rstd, w.detach())
         return y
 
@@ -371,7 +375,7 @@ class LayerNormFn(Function):
         dg, db, dsum = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
         dx, dx16 = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), dxsum=dsum)
         _put_shadow(dx, dx16, dsum)
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -506,7 +510,7 @@ def vit_forward(m, image, adt):
         x = ViTBlockFn.apply(x, m.num_heads, adt, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
                              blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
                              blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-    return LayerNormFn.apply(x, m.norm.weight, m.norm.bias, 1e-6)
+    return LayerNormFn.apply(x, m.norm.weight, m.norm.bias, 1e-6, adt)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -844,15 +848,42 @@ def bert_forward(m, input_ids, attention_mask, adt, training=False, seed=0):
 # ------------------------------------------------------------------------------------------------------------------
 # heads
 # ------------------------------------------------------------------------------------------------------------------
+_SKIP_MASKS = {}
+
+
+def _skip_mask(B, N, skip, device):
+    key = (B, N, skip, str(device))
+    m = _SKIP_MASKS.get(key)
+    if m is None:
+        if len(_SKIP_MASKS) > 16:
+            _SKIP_MASKS.clear()
+        m = torch.ones(B, N, device=device, dtype=torch.int64)
+        m[:, :skip] = 0
+        _SKIP_MASKS[key] = m
+    return m
+
+
 class ProjectPoolFn(_GradAwareFn):
     """SimpleProjection -> TopKPooling(LoDA) -> L2norm  (pipelines/clip.py:87-93, 111-120) as one node:
     the [B,N,512] token projection lives only inside this function."""
 
     @staticmethod
-    def forward(ctx, feats, w, k, mask, adt):
+    def forward(ctx, feats, w, k, mask, adt, skip=0):
+        # skip = s: the first s tokens of every sequence take no part in the pooling (the image tower's [cls] token: the reference pools
+        # feats[:, 1:], clip.py:65-84).  Handing the tower's whole output over and masking the token here saves the slice's copy of the
+        # features in the forward, the zero-filled scatter of its gradient in the backward and - with the 16-bit copy the tower's last
+        # LayerNorm wrote (feats._simseg_fwd16) - the cast: four passes over [B, N, D] per step.  Same pooled values, same gradients.
         B, N, D = feats.shape
-        f2 = feats.contiguous().view(-1, D)
-        fa = f2 if adt == F32 else ops.cast(f2, adt)
+        if skip:
+            if mask is not None:
+                raise ValueError("ProjectPoolFn: skip and a token mask together are not supported")
+            mask = _skip_mask(B, N, int(skip), feats.device)
+        sh16 = getattr(feats, "_simseg_fwd16", None) if adt != F32 else None
+        if sh16 is not None and sh16[1] == feats._version and sh16[0].shape == feats.shape and sh16[0].dtype == adt:
+            fa = sh16[0].view(-1, D)
+        else:
+            f2 = feats.contiguous().view(-1, D)
+            fa = f2 if adt == F32 else ops.cast(f2, adt)
         ctx.adt, ctx.k, ctx.dims = adt, k, (B, N, D)
         if not _saving(ctx):
             tok = _fwd_gemm(fa, w, adt, False).view(B, N, w.shape[0])
@@ -871,4 +902,4 @@ class ProjectPoolFn(_GradAwareFn):
         dtok = ops.topk_pool_l2norm_bwd(demb.contiguous(), emb, norm, idx, N, ctx.adt).view(B * N, -1)
         dfe = _dgrad(dtok, wa, out_dtype=F32).view(B, N, D) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dtok, fa) if ctx.needs_input_grad[1] else None
-        return dfe, dw, None, None, None
+        return dfe, dw, None, None, None, None

@@ -624,3 +624,37 @@ def test_training_trajectory_follows_oracle(golden, monkeypatch):
     assert abs(ours[0] - want[0]) < 2e-2 * want[0]
     for a, b in zip(ours[:10], want[:10]):                     # early steps: same curve (later ones diverge chaotically in any precision)
         assert abs(a - b) < 0.1 * max(abs(b), 0.1), (ours[:10], want[:10])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_fused_image_head_equals_slice_project_pool(golden, monkeypatch, mode):
+    """CLIPModel._image_embeddings hands the image tower's WHOLE output to ProjectPoolFn (skip=1: the [cls] token is masked out of the top-k
+    pooling; the 16-bit copy written by the tower's last LayerNorm is the GEMM operand) instead of slicing feats[:, 1:] first (clip.py:65-84,
+    87-93).  Same embeddings bit for bit; same gradients up to the order of the weight-gradient atomics."""
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+    g = golden("clip_train_ws1")
+    image = tt(g["r0.image"]).cuda()
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SIMSEG_AMD_FUSED_IMAGE_HEAD", fused)
+        m = _build(golden).eval()
+        emb = m._image_embeddings(image)
+        (emb * torch.linspace(-1, 1, emb.numel(), device="cuda").view_as(emb)).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = (emb.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert set(res["1"][1]) == set(res["0"][1]) and len(res["1"][1]) > 10
+    for n, ga in res["1"][1].items():
+        gb = res["0"][1][n]
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12, n
+    # ... and it is what forward() runs
+    m = _build(golden).eval()
+    monkeypatch.setenv("SIMSEG_AMD_FUSED_IMAGE_HEAD", "1")
+    from simseg_amd import towers
+    hits = []
+    real = towers.ProjectPoolFn.forward
+    monkeypatch.setattr(towers.ProjectPoolFn, "forward", staticmethod(lambda ctx, *a: (hits.append(a[5] if len(a) > 5 else 0), real(ctx, *a))[1]))
+    batch = {"image": image, "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    m(batch)
+    assert 1 in hits
