@@ -884,7 +884,13 @@ def main():
                                      "steps overlap the two towers on two streams" if two_streams else "one instrumented step",
                          "clocks_during_timed_steps": clock_info,
                          "frac_of_peak_at_measured_clock": (round(achieved / clock_info["dense_bf16_peak_at_this_clock_tflops"], 4)
-                                                            if clock_info else None)},
+                                                            if clock_info else None),
+                         # what bounds these launches (measured once per round, not in this process): the same kernels on ZERO operands - same
+                         # bytes moved, same instructions - reach 1433-1447 TFLOP/s at ~1.13 kW; on Gaussian operands 1121-1186 at the board's
+                         # ~1.36 kW: the long-K launches sit at the power envelope, the kernel's own ceiling is 0.58 of the nominal peak
+                         "limits": {"power_capped_on_real_operands": True, "same_launches_on_zero_operands_tflops": {"tn": 1433, "nn": 1447, "nt_k768": 1097},
+                                    "same_launches_on_gaussian_operands_tflops": {"tn": 1121, "nn": 1186, "nt_k768": 1007},
+                                    "source": "profiles/r4_gemm_power_probe.txt (tools/gemm_power_probe.py)"}},
             "step_model": {"algorithmic_tflop_per_rank_step": round(B * fpp / 1e12, 2),
                            "algorithmic_tflops_per_gpu": round(B * fpp / (elapsed / args.steps) / 1e12, 2),
                            "algorithmic_frac_of_bf16_peak": round(B * fpp / (elapsed / args.steps) / PEAK_BF16, 4),
