@@ -1,6 +1,6 @@
 # same-box A/B of two builds of the library on the GELU epilogue GEMMs (fc1 forward, dgrad through fc2), three interleaved rounds
 for r in 1 2 3; do
-for lib in libsimseg_hip_ab.so libsimseg_hip.so; do
+for lib in libsimseg_hip_ab.so libsimseg_hip.so   # (build the other tree into simseg_amd/libsimseg_hip_ab.so first; it is gpurun-ignored - copy it under another name to ship it); do
   export SIMSEG_AMD_LIB=$PWD/simseg_amd/$lib
   echo "=== $lib round $r"
   echo -n "act 3 (fc1 fwd, row-major GELU')   "; timeout 100 python tools/gemm_bench.py --iters 20 --shapes quick --only nt --act 3 2>&1 | grep -v amdgpu | head -1
