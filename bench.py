@@ -638,6 +638,13 @@ def main():
         else:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
     opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    # single process, two tower streams: the text tower's parameters are updated on the text tower's stream, i.e. as soon as ITS backward
+    # has finished, beside the rest of the image tower's backward (SIMSEG_BENCH_OPT_STREAMS=0: one launch behind everything, as before)
+    OPT_STREAMS = world == 1 and sync is None and os.environ.get("SIMSEG_BENCH_OPT_STREAMS", "1") != "0"
+    if OPT_STREAMS:
+        from simseg.models.pipelines.clip import _side_stream
+        side_ = _side_stream(dev)
+        opt.set_param_streams({p: side_ for p in list(model.text_encoder.parameters()) + list(model.text_projection.parameters())})
     B, L = args.pairs_per_gpu, args.seq_len
     # NB pre-generated device batches, visited round-robin; the caption tensors handed to the model are FRESH tensor objects every
     # step (a clone, as a loader delivers them), so whatever the model derives from a mask - towers.ragged_maps with its host read of
@@ -666,7 +673,7 @@ def main():
         loss_dict["nce_loss"].backward()
         if sync is not None:
             sync()
-        opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0)
+        opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0, param_streams=bool(getattr(model, "two_streams_used", False)))
         return loss_dict["nce_loss"]
 
     bdf = None
@@ -868,6 +875,7 @@ def main():
                                          else ("none" if world == 1 else "torch DDP")),
                        "gradient_sync_detail": ({"zero_copy_weight_gradients": ZERO_COPY, "gradients_copied_per_step": sync.copied_last,
                                                  "events_per_step": sync.events_last, "buckets": len(sync.buckets)} if sync is not None else None),
+                       "optimizer_streams": ("text tower's parameters updated on its own stream (starts when that tower's backward ends)" if OPT_STREAMS else "one launch on the main stream"),
                        "tower_streams": 2 if two_streams else 1,
                        "persistent_gemm_reserved_cus": int(os.environ.get("SIMSEG_GEMM_PP2_RESERVE", "0")),
                        "bert_dropout": 0.1, "optimizer": "AdamW (fused HIP kernel)",

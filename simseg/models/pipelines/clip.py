@@ -122,7 +122,8 @@ class CLIPModel(nn.Module):
         # host->device copy).  With them the text tower sizes its packed rows without reading anything back from the GPU.
         lengths = batch.get("caption_lengths") if isinstance(batch, dict) else None
         discard_prefetched(logger.warning)           # gathers of an earlier step that never reached the loss
-        if image.is_cuda and _two_streams_ok():
+        self.two_streams_used = bool(image.is_cuda and _two_streams_ok())      # (read by callers that launch per-tower work on the tower's stream)
+        if self.two_streams_used:
             # The two towers are independent until the loss: the text tower runs on a second HIP stream so that its kernels
             # fill the CUs the image tower's kernels leave idle (partial last rounds of the 256-CU tile grids, memory-bound
             # LayerNorm / attention phases).  autograd replays each tower's backward on the stream its forward used.

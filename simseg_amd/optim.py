@@ -11,6 +11,8 @@ training step launches no weight-cast kernels.
 
 Checkpoints use torch.optim.AdamW's state layout ({step, exp_avg, exp_avg_sq} per parameter), so the reference's optimizer
 checkpoints (core/hooks/checkpoint.py:14-45) load here and ours load there; the bias-correction step counter travels with them."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -36,6 +38,21 @@ class AdamW(torch.optim.Optimizer):
         self._step_dev = None             # AMP: float32 [2] on the device, the count of steps actually TAKEN (skipped ones do not count)
         self._amp_calls = 0               #      which slot is current
         self._plans = {}
+        self._prepared = None
+        self._streams = {}                # id(parameter) -> stream its update is launched on (set_param_streams); default: the current stream
+
+    def set_param_streams(self, mapping):
+        """mapping: {parameter: torch.cuda.Stream or None}.  The update of those parameters is launched on that stream instead of the current
+        one - for a tower whose forward AND backward run on a stream of their own (the text tower of CLIPModel's two-stream schedule) it
+        then starts when that tower's backward ends instead of waiting behind the other tower's: ~0.5 ms of a 512-pair step.  The caller owns
+        the ordering: every later reader of these parameters (and of their 16-bit copies) must run on that stream or wait for it, and
+        their gradients must be complete on it (single-process training; with a gradient exchange leave them on the current stream)."""
+        for p_, st in mapping.items():
+            if st is None:
+                self._streams.pop(id(p_), None)
+            else:
+                self._streams[id(p_)] = st
+        self._plans.clear()
         self._prepared = None
 
     # ---- launch plan: everything about a set of tensors that does not change from step to step ------------------------------
@@ -81,7 +98,7 @@ class AdamW(torch.optim.Optimizer):
         self._plans[key] = plan
         return plan
 
-    def _prepare(self):
+    def _prepare(self, on_own=True):
         """Per-step tables of every bucket (gradient pointers, learning rates) uploaded; reused by the call that follows immediately
         (found_inf_check() then step() inside one scaler.step)."""
         grads_now = tuple(id(p.grad) for g in self.param_groups for p in g["params"])
@@ -89,9 +106,11 @@ class AdamW(torch.optim.Optimizer):
             return self._prepared[1]
         buckets = {}
         for group in self.param_groups:
-            key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
+            key0 = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
             for p in group["params"]:
                 if p.grad is not None:
+                    st = self._streams.get(id(p))
+                    key = key0 + ((st.cuda_stream,) if st is not None else ())
                     buckets.setdefault(key, []).append((p, float(group["lr"]), float(group["weight_decay"])))
         ready = []
         for key, items in buckets.items():
@@ -103,6 +122,7 @@ class AdamW(torch.optim.Optimizer):
                 self._plans.pop(key)
                 plan = self._plan(key, params)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
+            plan["stream"] = self._streams.get(id(params[0])) if (len(key) > 3 and on_own) else None      # where this step's upload + launch go
             slot = plan["slot"]
             plan["slot"] = (slot + 1) % RING
             if plan["events"][slot] is not None:
@@ -114,9 +134,10 @@ class AdamW(torch.optim.Optimizer):
             hyper[:, 0] = [it[1] for it in items]
             hyper[:, 1] = [it[2] for it in items]
             host[:, 5] = hyper.view(np.int64)[:, 0]
-            plan["table"].copy_(plan["ring"][slot], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            with (torch.cuda.stream(plan["stream"]) if plan["stream"] is not None else contextlib.nullcontext()):
+                plan["table"].copy_(plan["ring"][slot], non_blocking=True)      # (on the stream the kernel is launched on)
+                ev = torch.cuda.Event()
+                ev.record()
             plan["events"][slot] = ev
             plan["keepalive"] = grads        # the kernels read them asynchronously
             ready.append((key, plan, params))
@@ -128,7 +149,7 @@ class AdamW(torch.optim.Optimizer):
         """found_inf (float32 scalar tensor on the device) = 1 if any gradient holds an inf / nan: GradScaler's overflow check as one
         read-only launch per bucket over this optimizer's tensor table (simseg_amd.optim.GradScaler calls it instead of torch's
         read-modify-write pass over every gradient tensor)."""
-        for key, plan, params in self._prepare():
+        for key, plan, params in self._prepare(on_own=False):
             call("simseg_grads_nonfinite", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"], CHUNK,
                  ptr(found_inf), stream())
         return found_inf
@@ -140,11 +161,14 @@ class AdamW(torch.optim.Optimizer):
         return self._step
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, param_streams=True):
         # torch.amp.GradScaler.step() sets these two attributes around the call (and deletes them afterwards)
         loss_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
         amp = loss_scale is not None or found_inf is not None
-        ready = self._prepare()
+        # param_streams=False (or a GradScaler-driven step, whose overflow flag is produced on the current stream): every launch on the
+        # current stream, whatever set_param_streams said - the caller's backward did not run on those streams this time
+        on_own = param_streams and not amp
+        ready = self._prepare(on_own)
         self._prepared = None
         if amp:
             if self._step_dev is None:       # the device counter takes over from the host one
@@ -160,18 +184,20 @@ class AdamW(torch.optim.Optimizer):
                 self._step_dev = None
             self._step += 1
         for key, plan, params in ready:
-            note_half(self.half_dtype)        # (the 16-bit copies are addressed through the table: tell the binding which flavour they are)
-            if amp:
-                cur = self._amp_calls & 1
-                call("simseg_adamw_multi_step_amp", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
-                     CHUNK, key[0], key[1], key[2], float(grad_scale), ptr(loss_scale), ptr(found_inf), ptr(self._step_dev[cur:cur + 1]),
-                     ptr(self._step_dev[1 - cur:2 - cur]), stream())
-            else:
-                call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
-                     CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
-            for p in params:                 # same stream as the next forward: the copies are current when it runs
-                register_w16(p, self.state[p]["p16"])
-                drop_split_copy(p)           # the exact-mode split-bf16 copy of the OLD value (raw-pointer update: _version did not move)
+          own = plan.get("stream")
+          with (torch.cuda.stream(own) if own is not None else contextlib.nullcontext()):
+              note_half(self.half_dtype)        # (the 16-bit copies are addressed through the table: tell the binding which flavour they are)
+              if amp:
+                  cur = self._amp_calls & 1
+                  call("simseg_adamw_multi_step_amp", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
+                       CHUNK, key[0], key[1], key[2], float(grad_scale), ptr(loss_scale), ptr(found_inf), ptr(self._step_dev[cur:cur + 1]),
+                       ptr(self._step_dev[1 - cur:2 - cur]), stream())
+              else:
+                  call("simseg_adamw_multi_step", ptr(plan["table"]), ptr(plan["sizes"]), ptr(plan["tid"]), ptr(plan["coff"]), plan["n_chunks"],
+                       CHUNK, key[0], key[1], key[2], self._step, float(grad_scale), stream())
+              for p in params:                 # same stream as the next forward: the copies are current when it runs
+                  register_w16(p, self.state[p]["p16"])
+                  drop_split_copy(p)           # the exact-mode split-bf16 copy of the OLD value (raw-pointer update: _version did not move)
         if amp:
             self._amp_calls += 1             # (several buckets: every launch of this call read the same slot and wrote the other)
 

@@ -658,3 +658,44 @@ def test_fused_image_head_equals_slice_project_pool(golden, monkeypatch, mode):
     batch = {"image": image, "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
     m(batch)
     assert 1 in hits
+
+
+@pytest.mark.gpu
+def test_text_tower_update_on_its_own_stream_matches_single_launch(golden, monkeypatch):
+    """AdamW.set_param_streams: the text tower's parameters are updated on the text tower's stream (right behind its backward) instead of in
+    the one launch behind everything.  Same trajectory as the single launch over several steps, with fresh batches' memory recycled in
+    between (a missing ordering would show up as drift or garbage), and with a single-stream step in the middle (param_streams=False)."""
+    from simseg.models.pipelines.clip import _side_stream
+    from simseg_amd.optim import AdamW
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+    monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", "1")
+    g = golden("clip_train_ws1")
+    base = {"image": tt(g["r0.image"]).cuda(), "input_ids": tt(g["r0.input_ids"]).cuda(), "attention_mask": tt(g["r0.attention_mask"]).cuda()}
+    runs = {}
+    for own in (False, True):
+        m = _build(golden).eval()
+        opt = AdamW(m.parameters(), lr=1e-3)
+        if own:
+            opt.set_param_streams({p: _side_stream(torch.device("cuda", 0)) for p in list(m.text_encoder.parameters()) + list(m.text_projection.parameters())})
+        losses = []
+        for it in range(7):
+            batch = {k: v.clone() for k, v in base.items()}
+            if it == 3:
+                monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", "0")
+            opt.zero_grad(set_to_none=True)
+            loss = m(batch)[0]["nce_loss"]
+            loss.backward()
+            opt.step(param_streams=m.two_streams_used)
+            if it == 3:
+                assert not m.two_streams_used
+                monkeypatch.setenv("SIMSEG_AMD_TWO_STREAMS", "1")
+            losses.append(float(loss.detach()))
+            del batch
+            junk = torch.full((1 << 22,), float("nan"), device="cuda")      # recycled memory is poisoned
+            del junk
+        torch.cuda.synchronize()
+        runs[own] = (losses, {n: p.detach().clone() for n, p in m.named_parameters()})
+    l0, l1 = runs[False][0], runs[True][0]
+    assert all(np.isfinite(l1)) and max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3 * max(abs(x) for x in l0), (l0, l1)
+    worst = max(float((runs[False][1][n] - runs[True][1][n]).abs().max() / (runs[False][1][n].abs().max() + 1e-12)) for n in runs[False][1])
+    assert worst < 5e-2, worst
