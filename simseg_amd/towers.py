@@ -406,7 +406,11 @@ class ViTEmbedFn(_GradAwareFn):
         (cols,) = ctx.saved_tensors
         B, N, D = ctx.dims
         dx = dx.contiguous()
-        dp16 = _act_grad(dx[:, 1:].contiguous().view(-1, D), ctx.adt)
+        sh = _take_shadow(dx, ctx.adt) if ctx.adt != F32 else None
+        if sh is not None:       # the first block's backward left a 16-bit copy of dx: slice THAT (half the bytes of the fp32 slice, no cast pass; same bits)
+            dp16 = sh[0].view(B, N + 1, D)[:, 1:].contiguous().view(-1, D)
+        else:
+            dp16 = _act_grad(dx[:, 1:].contiguous().view(-1, D), ctx.adt)
         dw = _wgrad(dp16, cols).view(D, 3, 16, 16) if ctx.needs_input_grad[1] else None
         db = _bgrad(dp16) if ctx.needs_input_grad[2] else None
         dcls = dpos = None
