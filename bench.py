@@ -582,14 +582,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cpu = cpu_seg = cpu_retr = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.img, args.seq_len)
-        if not args.no_seg:
-            cpu_seg = cpu_baseline_seg()
-            log(f"cpu seg baseline: {cpu_seg}")
-            cpu_retr = cpu_baseline_retrieval()
-            log(f"cpu retrieval baseline: {cpu_retr}")
+    cpu = cpu_seg = cpu_retr = None       # (the CPU legs run AFTER every GPU leg, below: 30-60 s of 32-thread host work in front of the timed
+                                          #  steps once left a box's host side slow enough to starve the GPU - 93.5 instead of 87.6 ms per step)
 
     log("cpu baseline done" if cpu else "no cpu baseline")
     from simseg.core import init_device
@@ -815,6 +809,18 @@ def main():
             retr["cpu_baseline"] = cpu_retr
         os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
         log(f"retrieval eval: {retr}")
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.img, args.seq_len)
+        if not args.no_seg:
+            cpu_seg = cpu_baseline_seg()
+            log(f"cpu seg baseline: {cpu_seg}")
+            cpu_retr = cpu_baseline_retrieval()
+            log(f"cpu retrieval baseline: {cpu_retr}")
+            if seg is not None:
+                seg["cpu_baseline"] = cpu_seg
+            if retr is not None:
+                retr["cpu_baseline"] = cpu_retr
 
     if rank == 0:
         n_patches = (args.img // 16) ** 2
