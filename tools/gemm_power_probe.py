@@ -23,8 +23,9 @@ def sampler(stop, out):
             mhz = float("nan")
             for p in fq:
                 for line in open(p):
-                    if "*" in line:
-                        mhz = float(line.split(":")[1].strip().split("M")[0])
+                    if line.strip().endswith("*"):
+                        import re
+                        mhz = max(mhz if mhz == mhz else 0.0, float(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1)))      # (the busy card of a multi-GPU node)
             out.append((w, mhz))
         except Exception:       # noqa: BLE001
             pass
@@ -58,7 +59,7 @@ def run(name, a, b, kw, flops, secs=1.5):
 
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
-    for kind, M, N, K in (("nt", 100864, 3072, 768), ("nn", 100864, 768, 3072), ("tn", 3072, 768, 100864), ("nt", 8192, 8192, 8192)):
+    for kind, M, N, K in (("nt", 100864, 3072, 768), ("nn", 100864, 768, 3072), ("tn", 3072, 768, 100864)):
         print(f"{kind} M={M} N={N} K={K}")
         ta, tb = kind == "tn", kind in ("nn", "tn")
         sa = (K, M) if ta else (M, K)
@@ -71,9 +72,14 @@ def main():
         fl = 2.0 * M * N * K
         for name, mk in (("gaussian", lambda s: torch.randn(s, device="cuda", generator=g)),
                          ("sign only (+-1)", lambda s: torch.randn(s, device="cuda", generator=g).sign()),
+                         ("gaussian, weights x 0.02", None),
                          ("ones", lambda s: torch.ones(s, device="cuda")),
                          ("zeros", lambda s: torch.zeros(s, device="cuda"))):
-            a, b = mk(sa).bfloat16(), mk(sb).bfloat16()
+            if mk is None:       # realistic scales: the weight operand (B in nt / nn) ~N(0, 0.02^2); the weight gradient has two activation operands
+                a = torch.randn(sa, device="cuda", generator=g).bfloat16()
+                b = (torch.randn(sb, device="cuda", generator=g) * (1.0 if kind == "tn" else 0.02)).bfloat16()
+            else:
+                a, b = mk(sa).bfloat16(), mk(sb).bfloat16()
             run(name, a, b, kw, fl)
             del a, b
 
