@@ -796,6 +796,43 @@ def test_attention_fwd_persistent_loader_wave_kernel(ops, B, T, H):
     assert float((out4.double() - want).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("B,T,H,ragged,drop", [(5, 197, 12, False, 0.0), (9, 77, 4, True, 0.1), (3, 224, 2, False, 0.0), (6, 33, 3, True, 0.0)])
+def test_attention_on_plane_major_operands_equals_packed_rows(ops, B, T, H, ragged, drop):
+    """simseg_attention_{fwd,bwd}_planes: qkv / dqkv as [3 H][rows][64] (a head's operand rows one contiguous run) through the same resident
+    forward / one-kernel backward, addressed by two stride parameters - the bits of the packed-row entry points, dense and ragged batches,
+    dropout included, with the q/k/v bias gradient."""
+    g = torch.Generator(device="cuda").manual_seed(T)
+    if ragged:
+        lens = torch.randint(1, T + 1, (B,), device="cuda", generator=g)
+        rs = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+        rs[1:] = lens.cumsum(0)
+        n = int(rs[-1])
+        rows = (n + 255) // 256 * 256
+    else:
+        rs, n, rows = None, B * T, B * T
+    qkv = torch.randn(rows, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    qkvp = qkv.view(rows, 3 * H, 64).permute(1, 0, 2).contiguous()
+    kw = dict(drop_seed=77, drop_p=drop)
+    if ragged:
+        oa, la = ops.attention_fwd_rows(qkv, H, rs, T, save_lse=True, n_real=n, **kw)
+    else:
+        oa, la = ops.attention_fwd(qkv.view(B, T, -1), H, None, save_lse=True)
+        oa = oa.reshape(rows, -1)
+    ob, lb = ops.attention_fwd_planes(qkvp, H, B, T, rs, save_lse=True, n_real=n, **kw)
+    assert torch.equal(oa[:n], ob[:n])
+    if not ragged:
+        assert torch.equal(la, lb)
+    do = torch.randn(rows, H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    ca, cb = torch.zeros(3 * H * 64, device="cuda"), torch.zeros(3 * H * 64, device="cuda")
+    if ragged:
+        da = ops.attention_bwd_rows(qkv, oa, do, la, H, rs, T, n_real=n, colsum=ca, **kw)
+    else:
+        da = ops.attention_bwd(qkv.view(B, T, -1), oa.view(B, T, -1), do.view(B, T, -1), la, H, None, colsum=ca).reshape(rows, -1)
+    db = ops.attention_bwd_planes(qkvp, ob, do, lb, H, B, T, rs, n_real=n, colsum=cb, **kw)
+    assert torch.equal(da.view(rows, 3 * H, 64)[:n], db.permute(1, 0, 2)[:n])
+    assert torch.equal(ca, cb)
+
+
 def test_attention_masked_length_limit(ops):
     qkv = _rand(1, 1100, 3 * 64, seed=1, dtype=torch.bfloat16)
     mask = torch.ones(1, 1100, dtype=torch.long, device="cuda")
