@@ -407,3 +407,38 @@ def test_gradsync_zero_copy_targets():
         assert _grad_target(w1) is None              # not armed between steps
         sync.close()
         assert not hasattr(w1, "_simseg_grad_target")
+
+
+def test_gradsync_buckets_are_cut_at_stream_boundaries():
+    """GradSync._split_by_stream (round 4): a bucket whose gradients were produced on more than one stream is cut into its runs of same-stream
+    members (contiguous sub-ranges of the flat buffer); gradients that never arrived join the run they lie in; the exchange keeps working on
+    the new buckets.  (On the GPU the streams are the two towers'; here they are stand-ins.)"""
+    import torch
+    from simseg_amd.parallel import GradSync
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 3, 7, 2, 4, 6)]
+    sync = GradSync(ps, overlap=True)                     # one 64 MiB bucket, flat order = reversed registration order
+    assert len(sync.buckets) == 1 and sync.buckets[0]["members"] == [5, 4, 3, 2, 1, 0]
+    A, B = object(), object()
+    sync._prod = [A, A, None, B, B, A]                    # indexed by parameter: flat order 5..0 -> A, B, B, None, A, A
+    sync._split_by_stream()
+    assert [bk["members"] for bk in sync.buckets] == [[5], [4, 3, 2], [1, 0]]
+    lo = 0
+    for bk in sync.buckets:                               # contiguous, in flat order, sizes add up
+        assert bk["lo"] == lo and bk["n"] == sum(ps[i].numel() for i in bk["members"])
+        lo += bk["n"]
+    assert lo == sync.flat.numel() and sync._bucket_of == {5: 0, 4: 1, 3: 1, 2: 1, 1: 2, 0: 2}
+    sync._reset()
+    x = torch.arange(1.0, 8.0)
+    loss = sum((p * x[:p.numel()]).sum() for i, p in enumerate(ps) if i != 2)      # parameter 2 gets no gradient this step
+    loss.backward()
+    sync.finish()
+    for i, (p, v) in enumerate(zip(sync.params, sync.views)):
+        assert p.grad.data_ptr() == v.data_ptr()
+        assert torch.equal(p.grad, torch.zeros_like(p) if i == 2 else x[:p.numel()])
+    # a second call changes nothing (all runs are pure now)
+    sync._prod = [A, A, None, B, B, A]
+    before = [dict(bk) for bk in sync.buckets]
+    sync._split_by_stream()
+    assert [bk["members"] for bk in sync.buckets] == [bk["members"] for bk in before]
+    sync.close()
