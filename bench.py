@@ -722,6 +722,31 @@ def main():
         finally:
             os.environ["SIMSEG_AMD_PACKED_TEXT"] = "1"
 
+    # ---- the same step with the saved GELU' as a 16-bit image (round 3's form; the default is the 8-bit image of simseg_gemm act 7 / 8,
+    # equally accurate for the product it feeds - include/simseg_hip.h).  Secondary figure, same process.
+    gelu16 = None
+    from simseg_amd import towers as _tw
+    if _tw._GELU8 and os.environ.get("SIMSEG_BENCH_GELU16_LEG", "1") != "0":
+        _tw._GELU8 = False
+        try:
+            for _ in range(2):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el4 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(el4, op=dist.ReduceOp.MAX)
+            gelu16 = {"pairs_per_s": round(world * B * args.steps / float(el4), 2), "ms_per_step": round(1e3 * float(el4) / args.steps, 3)}
+        finally:
+            _tw._GELU8 = True
+
     # ---- the same step in the reference's own AMP type: fp16 compute + a live GradScaler (clip_runner.py:226-230, core/hooks/
     # optimizer.py:73-82) - the fp16 flavour of the same kernels (secondary figure, same process; single-rank runs only: the scaler's
     # skip decision is per rank)
@@ -918,7 +943,10 @@ def main():
                            "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4),
-                           "with_padded_caption_tokens_computed": dense_text, "fp16_amp_with_gradscaler": fp16_amp},
+                           "with_padded_caption_tokens_computed": dense_text, "with_16bit_gelu_derivative_image": gelu16,
+                           "gelu_derivative_image": ("8-bit (simseg_gemm act 7 / 8: uniform grid over GELU''s range; the product it feeds is as accurate as with the "
+                                                     "16-bit image - tests/test_gpu_kernels.py)" if _tw._GELU8 else "16-bit"),
+                           "fp16_amp_with_gradscaler": fp16_amp},
             "seg_eval": seg,
             "retrieval_eval": retr,
             "cpu_baseline": cpu,

@@ -863,6 +863,9 @@ struct PPFrag {
 // operand sets for 3; a second converted accumulator block for 2): compiled into EVERY bf16-output kernel, state that lives across the K loop is
 // parked in scratch around every tile of every launch (round 3 ended with 22-75 spilled VGPRs in all of them), so each kind has instantiations
 // of its own and the plain kernels - most launches of the step - carry none of it (tests/test_host_logic.py reads .vgpr_spill_count).
+// 8-bit image of the saved GELU' (simseg_gemm act 7 / 8): q = round((g + 0.132) * 255 / 1.264), g in [-0.1290, 1.1290]
+constexpr float GELU8_SCALE = 255.0f / 1.264f, GELU8_OFF = 0.132f * (255.0f / 1.264f);
+
 template <int EK = 1>
 __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x16 (&acc)[4][2], char* tl, int m0, int c0, int c1, int grp, int lane) {
     constexpr int TP = 72;                                   // bytes per staged column (32 rows x 2 B + 8 B pad: conflict-free)
@@ -905,7 +908,38 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
     // (one rounding, exact column sums from two registers) and stores through the plain path.  Opaque to everything else: the tensor
     // is only ever handed from the one call to the other.
     const long blk0 = ((((long)(m0 >> 8) * (p.N >> 8) + (c0 >> 8)) * 8 + grp * 4 + ((c0 & 255) >> 5)) * 8) * 1024 + lane * 16;      // + (i * 2 + j) * 1024
-    if (EK == 3 && p.act == 4 && p.aux_blocked) {
+    if (EK == 5 && p.act == 4 && p.aux_blocked == 2) {
+        // act 8: times the 8-bit derivative image of act 7 (16 bytes per lane and 32-row block column: half the loads, half the operand registers)
+        const unsigned char* A8 = reinterpret_cast<const unsigned char*>(p.aux) + blk0;
+        u32x4 a8[2][2];                                      // [buffer][j]: the 16 rows of the left / right column, one byte each
+        auto load8 = [&](int i, u32x4 (&dst)[2]) {
+            dst[0] = *reinterpret_cast<const u32x4*>(A8 + (i * 2) * 1024);
+            dst[1] = *reinterpret_cast<const u32x4*>(A8 + (i * 2 + 1) * 1024);
+        };
+        load8(0, a8[0]);
+        f32x2 sLR = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) load8(i + 1, a8[(i + 1) & 1]);
+            f32x16 l, r;
+            union { u32x4 v; unsigned w[4]; } gl, gr;
+            gl.v = a8[i & 1][0]; gr.v = a8[i & 1][1];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const f32x2 q = {(float)((gl.w[e >> 2] >> (8 * (e & 3))) & 0xffu), (float)((gr.w[e >> 2] >> (8 * (e & 3))) & 0xffu)};      // v_cvt_f32_ubyteN
+                const f32x2 gd = pk_fma(q, (f32x2){1.0f / GELU8_SCALE, 1.0f / GELU8_SCALE}, -GELU8_OFF / GELU8_SCALE);
+                const f32x2 v = __builtin_elementwise_fma((f32x2){acc[i][0][e], acc[i][1][e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR}) * gd;
+                l[e] = v.x; r[e] = v.y;
+                sLR += v;
+            }
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+        if (p.colsum) {
+            float sL = sLR.x, sR = sLR.y;
+            sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
+            if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
+        }
+    } else if (EK == 3 && p.act == 4 && p.aux_blocked == 1) {
         const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.aux) + blk0;
         u32x4 ax[2][4];                                      // [buffer][j * 2 + half]: 16 rows of the left / right column
         // (one operand set requested right after the previous one is consumed, or scheduling barriers between the blocks, leave the
@@ -940,7 +974,36 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             sL += __shfl_xor(sL, 32, 64); sR += __shfl_xor(sR, 32, 64);
             if (lane < 32) { atomicAdd(p.colsum + c0 + cl, sL); atomicAdd(p.colsum + c1 + cl, sR); }
         }
-    } else if (EK == 2 && p.act == 3 && Xb && p.aux_blocked) {
+    } else if (EK == 4 && p.act == 3 && Xb && p.aux_blocked == 2) {
+        // act 7: the same image with ONE BYTE per element - GELU' lies in [-0.129, 1.129], stored as round((g + 0.132) * 255 / 1.264): a
+        // uniform 0.005 grid, i.e. finer than a 16-bit float's spacing where most of the gradient's energy is (g in [0.5, 1.13]: bf16
+        // steps of 0.004-0.008) and coarser only where |g| is small.  Relative RMS error of the product dY * g after its own rounding:
+        // 2.7e-3 against 2.5e-3 with the 16-bit image (tests/test_gpu_kernels.py) - at half of the step's largest epilogue stream.
+        unsigned char* B8 = reinterpret_cast<unsigned char*>(p.aux_out) + blk0;       // (blk0 counts elements: one byte each here)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x16 l, r;
+            union { u32x4 v; unsigned w[4]; } ql, qr;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                unsigned pl = 0, pr = 0;
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const int e = 4 * w4 + b4;
+                    f32x2 d;
+                    const f32x2 y = gelu_poly_grad2(__builtin_elementwise_fma((f32x2){acc[i][0][e], acc[i][1][e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR}), d);
+                    l[e] = y.x; r[e] = y.y;
+                    const f32x2 t = pk_fma(d, (f32x2){GELU8_SCALE, GELU8_SCALE}, GELU8_OFF + 0.5f);      // truncation below = round to nearest
+                    pl |= (unsigned)__builtin_amdgcn_fmed3f(t.x, 0.f, 255.f) << (8 * b4);      // (the clamp: a polynomial value a hair outside the range must not carry into the next byte)
+                    pr |= (unsigned)__builtin_amdgcn_fmed3f(t.y, 0.f, 255.f) << (8 * b4);
+                }
+                ql.w[w4] = pl; qr.w[w4] = pr;
+            }
+            *reinterpret_cast<u32x4*>(B8 + (i * 2) * 1024) = ql.v;
+            *reinterpret_cast<u32x4*>(B8 + (i * 2 + 1) * 1024) = qr.v;
+            emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+        }
+    } else if (EK == 2 && p.act == 3 && Xb && p.aux_blocked == 1) {
         bf16_t* Bb = Xb + blk0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1323,7 +1386,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         // bf16, staged TRANSPOSED ([column][row], 8-byte writes) and read back through ds_read_b64_tr_b16, which hands every lane 4
         // consecutive columns of one row: two reads = one 16-byte store.  ~70 instructions per block.
         const bool fastep = !atomic && vec_ok && !p.residual && !p.rowscale && p.row_group == 0 && !p.drop_thresh && !p.dbg_skip_epilogue &&
-                            (p.act == 0 || p.act == 1 || (p.act == 3 && (!p.aux_blocked || EK == 2)) || (((EK == 1 && !p.aux_blocked) || (EK == 3 && p.aux_blocked)) && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
+                            (p.act == 0 || p.act == 1 || (p.act == 3 && (!p.aux_blocked || (EK == 2 && p.aux_blocked == 1) || (EK == 4 && p.aux_blocked == 2))) ||
+                             (((EK == 1 && !p.aux_blocked) || (EK == 3 && p.aux_blocked == 1) || (EK == 5 && p.aux_blocked == 2)) && p.act == 4 && p.aux)) && (p.act == 4 || !p.colsum) &&
                             m0 + 256 <= p.M && n0 + 256 <= p.N;
         if (fastep) {
             pp_epilogue_bf16<EK>(p, acc, reinterpret_cast<char*>(wlds), m0, c0, c1, grp, lane);
@@ -1813,8 +1877,10 @@ template <typename TO, bool TA, bool TB>
 int launch_pp2_ek(const GemmParams& p, hipStream_t s, int reserve) {
     if constexpr (sizeof(TO) == 2) {      // (the kinds exist for 16-bit outputs only; the blocked image: fc1 forward = NT, dgrad through fc2 = NN)
         if (p.act == 4 && !p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 1>(p, s, reserve);
-        if constexpr (!TB) { if (p.act == 3 && p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 2>(p, s, reserve); }
-        if constexpr (TB) { if (p.act == 4 && p.aux_blocked) return launch_pp2<TO, TA, TB, 0, 3>(p, s, reserve); }
+        if constexpr (!TB) { if (p.act == 3 && p.aux_blocked == 1) return launch_pp2<TO, TA, TB, 0, 2>(p, s, reserve); }
+        if constexpr (TB) { if (p.act == 4 && p.aux_blocked == 1) return launch_pp2<TO, TA, TB, 0, 3>(p, s, reserve); }
+        if constexpr (!TB) { if (p.act == 3 && p.aux_blocked == 2) return launch_pp2<TO, TA, TB, 0, 4>(p, s, reserve); }
+        if constexpr (TB) { if (p.act == 4 && p.aux_blocked == 2) return launch_pp2<TO, TA, TB, 0, 5>(p, s, reserve); }
     }
     if (p.aux_blocked) return simseg_set_error("simseg_gemm: act 5 is a forward (x . W^T) epilogue, act 6 a dgrad (d . W) epilogue, both with 16-bit outputs");
     return launch_pp2<TO, TA, TB, 0, 0>(p, s, reserve);
@@ -1915,8 +1981,10 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
         // 16-MFMA phases (round 3) unless variant 15 asks for the four-phase schedule (A/B runs)
         if (!four_phase && p.K >= 128) {
             if constexpr (sizeof(TO) == 2 && !TA) {
-                if constexpr (!TB) { if (p.act == 3 && p.aux_blocked) return launch_pp<TO, TA, TB, 4, 1, 1, 2>(p, splitk, s); }
-                if constexpr (TB) { if (p.act == 4 && p.aux_blocked) return launch_pp<TO, TA, TB, 4, 1, 1, 3>(p, splitk, s); }
+                if constexpr (!TB) { if (p.act == 3 && p.aux_blocked == 1) return launch_pp<TO, TA, TB, 4, 1, 1, 2>(p, splitk, s); }
+                if constexpr (TB) { if (p.act == 4 && p.aux_blocked == 1) return launch_pp<TO, TA, TB, 4, 1, 1, 3>(p, splitk, s); }
+                if constexpr (!TB) { if (p.act == 3 && p.aux_blocked == 2) return launch_pp<TO, TA, TB, 4, 1, 1, 4>(p, splitk, s); }
+                if constexpr (TB) { if (p.act == 4 && p.aux_blocked == 2) return launch_pp<TO, TA, TB, 4, 1, 1, 5>(p, splitk, s); }
             }
             if (p.aux_blocked) return simseg_set_error("simseg_gemm: act 5 is a forward (x . W^T) epilogue, act 6 a dgrad (d . W) epilogue");
             if (sizeof(TO) == 2 && p.act != 4) return launch_pp<TO, TA, TB, 4, 1, 1, 0>(p, splitk, s);
@@ -2002,14 +2070,15 @@ extern "C" int simseg_gemm(const void* A, const void* B, void* C, int64_t M, int
     SS_CHECK(splitk <= 1 || (out_dtype == 0 && act == 0 && !bias && !residual && drop_p == 0.f && !colsum),
              "simseg_gemm: split-K needs a plain fp32 accumulate epilogue");
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "simseg_gemm: dropout p out of range");
-    SS_CHECK(act >= 0 && act <= 6, "simseg_gemm: act must be 0..6");
-    const int blocked = act >= 5;
-    if (blocked) {       // 5 / 6 = 3 / 4 with the saved derivative as the tile-blocked accumulator image (include/simseg_hip.h)
+    SS_CHECK(act >= 0 && act <= 8, "simseg_gemm: act must be 0..8");
+    const int blocked = act >= 7 ? 2 : (act >= 5 ? 1 : 0);
+    if (blocked) {       // 5 / 6 = 3 / 4 with the saved derivative as the tile-blocked accumulator image, 7 / 8 = the same image in 8 bits (include/simseg_hip.h)
+        const bool fwd = act == 5 || act == 7;
         SS_CHECK(simseg_gemm_aux_blocked_ok(M, N, K) && in_dtype == 1 && out_dtype == 1 && !transA && !rowscale && !residual && row_group == 0 &&
-                 drop_p == 0.f && splitk <= 1 && ldc == N && (act == 5 ? aux_out != nullptr : aux != nullptr) &&
-                 ((uintptr_t)(act == 5 ? aux_out : aux) % 16) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
+                 drop_p == 0.f && splitk <= 1 && ldc == N && (fwd ? aux_out != nullptr : aux != nullptr) &&
+                 ((uintptr_t)(fwd ? aux_out : aux) % 16) == 0 && ((uintptr_t)C % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                  "simseg_gemm: act %d needs a full-tile 16-bit problem on the ping-pong kernel (simseg_gemm_aux_blocked_ok) with a plain epilogue", act);
-        act -= 2;
+        act = fwd ? 3 : 4;
     }
     SS_CHECK((act != 2 && act != 4) || aux, "simseg_gemm: act=2/4 needs aux");
     SS_CHECK(!res_mod || row_group > 0, "simseg_gemm: res_mod needs row_group");

@@ -65,7 +65,11 @@ def gemm(a, b, *, trans_a=False, trans_b=False, out=None, out_dtype=None, alpha=
     kb = b.shape[0] if trans_b else b.shape[1]
     if kb != K:
         raise ValueError(f"gemm: inner dims differ ({K} vs {kb})")
-    if a.dtype != b.dtype or (aux is not None and aux.dtype not in (a.dtype, torch.float32)):
+    if act in (7, 8):       # the 8-bit tile-blocked derivative image (include/simseg_hip.h): an opaque [M, N] byte tensor
+        t8 = aux_out if act == 7 else aux
+        if t8 is None or t8.dtype != torch.uint8 or t8.numel() < a.shape[0] * (b.shape[1] if trans_b else b.shape[0]):
+            raise TypeError("gemm: act 7 / 8 take the derivative image as a uint8 tensor of M x N bytes")
+    if a.dtype != b.dtype or (aux is not None and act != 8 and aux.dtype not in (a.dtype, torch.float32)):
         raise TypeError(f"gemm: operands of different types ({a.dtype}, {b.dtype}{'' if aux is None else ', aux ' + str(aux.dtype)}): bf16 and fp16 do not mix in one call")
     if out is None:
         rows = out_rows if out_rows is not None else M

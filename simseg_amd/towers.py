@@ -181,6 +181,13 @@ def _zeros(device, *shapes):
     return [buf[a:a + n].view(sh) for a, n, sh in zip(offs, sizes, shapes)]
 
 
+# The saved GELU' of the MLP blocks as an 8-bit image (simseg_gemm act 7 / 8) instead of a 16-bit one (5 / 6): half of the step's largest
+# epilogue stream (1.24 GB per ViT-B layer written + read) at the same accuracy of the product it feeds - relative RMS error 2.7e-3 against
+# 2.5e-3, the product's own rounding to 16 bits being 1.7e-3 (tests/test_gpu_kernels.py).  SIMSEG_AMD_GELU_GRAD_BITS=16: the
+# 16-bit image.
+_GELU8 = os.environ.get("SIMSEG_AMD_GELU_GRAD_BITS", "8") != "16"
+
+
 def _grad_target(p):
     """Where a data-parallel gradient exchange wants parameter p's gradient written: a fresh, zero-filled view of its flat buffer
     (simseg_amd/parallel.py GradSync.begin()) - the split-K weight-gradient GEMMs accumulate into a zeroed output anyway, and autograd adopts
@@ -453,12 +460,14 @@ class ViTBlockFn(_GradAwareFn):
         att, lse = ops.attention_fwd(qkv.view(B, T, 3 * D), heads, None, scale=64 ** -0.5, save_lse=save)
         x1 = ops.gemm(att.view(-1, D), pw_, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
         ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=save)
-        pre = torch.empty(B * T, 4 * D, device=x.device, dtype=adt) if save else None
-        # (16-bit modes, full tiles: GELU' is saved as the tile-blocked accumulator image the dgrad through fc2 reads back - act 5 / 6)
+        # (16-bit modes, full tiles: GELU' is saved as the tile-blocked accumulator image the dgrad through fc2 reads back - act 5 / 6, or
+        #  7 / 8 = the same image with one byte per element, _GELU8)
         blk = save and adt != F32 and ops.gemm_aux_blocked_ok(B * T, 4 * D, D)
-        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=(5 if blk else 3) if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
+        g8 = blk and _GELU8
+        pre = torch.empty(B * T, 4 * D, device=x.device, dtype=torch.uint8 if g8 else adt) if save else None
+        act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=((7 if g8 else 5) if blk else 3) if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
         y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
-        ctx.adt, ctx.heads, ctx.dims, ctx.blk = adt, heads, (B, T, D), blk
+        ctx.adt, ctx.heads, ctx.dims, ctx.blk = adt, heads, (B, T, D), (2 if g8 else 1) if blk else 0
         ctx.wparams = (f2w, f1w, pw, qw)                                  # (the parameter objects: _grad_target in the backward)
         if save:
             ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_,
@@ -485,7 +494,7 @@ class ViTBlockFn(_GradAwareFn):
             dy.device, (None, tg[0], tg[1], None, None, None, tg[2], tg[3], None, None, None, None),
             (4 * D,), (D, 4 * D), (4 * D, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,), (D,), (D,), (D,))
         # mlp
-        dpre = _dgrad(dy16, f2w_, act=6 if ctx.blk else 4, aux=pre, colsum=df1b)
+        dpre = _dgrad(dy16, f2w_, act=(4, 6, 8)[ctx.blk], aux=pre, colsum=df1b)
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
         dln2 = _dgrad(dpre, f1w_)
         df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
@@ -726,14 +735,15 @@ class BertLayerFn(_GradAwareFn):
         s1 = _fwd_gemm(att.view(-1, D), ow, adt, save, bias=ob.detach(), residual=x.view(-1, D), out_dtype=F32, drop_seed=seed + 1, drop_p=drop_p)
         a32, a16, mean_a, rstd_a = ops.layernorm_fwd(s1, law.detach(), lab.detach(), 1e-12, want_bf16_copy=(adt if adt != F32 else False), save_stats=save)
         aa = a32 if adt == F32 else a16
-        pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=adt) if save else None
         blk = save and adt != F32 and ops.gemm_aux_blocked_ok(aa.shape[0], iw.shape[0], D)
-        act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=(5 if blk else 3) if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
+        g8 = blk and _GELU8
+        pre = torch.empty(x.shape[0] if packed else B * L, iw.shape[0], device=x.device, dtype=torch.uint8 if g8 else adt) if save else None
+        act = _fwd_gemm(aa, iw, adt, save, bias=ib.detach(), act=((7 if g8 else 5) if blk else 3) if save else 1, aux_out=pre)       # pre holds GELU'(intermediate)
         s2 = _fwd_gemm(act, o2w, adt, save, bias=o2b.detach(), residual=a32, out_dtype=F32, drop_seed=seed + 2, drop_p=drop_p)
         y, y16, mean_o, rstd_o = ops.layernorm_fwd(s2, low.detach(), lob.detach(), 1e-12, want_bf16_copy=(adt if (adt != F32 and packed) else False), save_stats=save)
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)                            # picked up by the next layer's forward (same tensor object)
-        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv, ctx.blk = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv, blk
+        ctx.adt, ctx.heads, ctx.dims, ctx.drop, ctx.packed, ctx.rows, ctx.nv, ctx.blk = adt, heads, (B, L, D), (drop_p, seed), packed, rows, nv, (2 if g8 else 1) if blk else 0
         ctx.wparams = (o2w, iw, ow)                                       # (the parameter objects: _grad_target in the backward)
         if save:
             ctx.save_for_backward(xa, mask, qkv, att, lse, s1, mean_a, rstd_a, aa, pre, act, s2, mean_o, rstd_o, wqkv, ow_, iw_, o2w_,
@@ -757,7 +767,7 @@ class BertLayerFn(_GradAwareFn):
             (D,), (D,), (D,), (I,), (D, I), (I, D), (D,), (D,), (D,), (D, D), (3 * D, D), (3 * D,))
         ds2_32, d2 = _ln_bwd(adt, s2, mean_o, rstd_o, low, dlow, dlob, None if adt != F32 else dy, dy32=dy if adt != F32 else None,
                              dxsum=do2b, drop=(p, seed + 2))
-        dpre = _dgrad(d2, o2w_, act=6 if ctx.blk else 4, aux=pre, colsum=dib)
+        dpre = _dgrad(d2, o2w_, act=(4, 6, 8)[ctx.blk], aux=pre, colsum=dib)
         do2w = _wgrad(d2, act, do2w_z) if need[18] else None
         # gradient reaching LN_a's output: through the intermediate dense (da) + the residual branch (ds2_32); bf16 mode adds them
         # inside the LayerNorm kernel, exact mode in the GEMM's residual epilogue

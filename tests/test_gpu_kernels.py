@@ -1061,9 +1061,25 @@ def test_gemm_saved_derivative_as_tile_blocked_image(ops, M, N, K, variant):
         _close(dx_blk, want, 1e-2, "times the tile-blocked derivative")
         _close(dx_row, want, 1e-2, "times the row-major derivative")
         _close(cs_blk, want.sum(0), 2e-4, "column sums (fp32 products)")
+        # act 7 / 8: the same image with one byte per element (uniform grid of 1.264 / 255 over GELU''s range): same forward output; the
+        # backward product is as accurate against the exact derivative as with the 16-bit image (both measured against fp64)
+        d8 = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+        y8 = ops.gemm(a, b, bias=bias, act=7, aux_out=d8)
+        assert torch.equal(y8, y_row)
+        cs8 = torch.zeros(N, device="cuda")
+        dx8 = ops.gemm(g, w2, trans_b=True, act=8, aux=d8, colsum=cs8)
+        pre = a.double() @ b.double().t() + bias.double()
+        gexact = 0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-pre * pre / 2) / (2 * 3.141592653589793) ** 0.5
+        exact = (g.double() @ w2.double()) * gexact
+        rms = lambda t: float(((t.double() - exact) ** 2).mean().sqrt() / (exact ** 2).mean().sqrt())     # noqa: E731
+        e16, e8 = rms(dx_blk), rms(dx8)
+        assert e8 < 1.25 * e16 + 1e-4 and e8 < 5e-3, (e16, e8)
+        assert float((dx8.float() - want).abs().max()) <= 4e-3 * float((g.float() @ w2.float()).abs().max()) + 1e-2 * float(want.abs().max())
+        _close(cs8, dx8.float().sum(0), 2e-3, "column sums of the 8-bit product")
         # the other kernel reads what this one wrote
         ops.set_gemm_variant(3 if variant == 0 else 0)
         _close(ops.gemm(g, w2, trans_b=True, act=6, aux=d_blk), dx_blk.float(), 1e-6, "blocked image across kernels")
+        _close(ops.gemm(g, w2, trans_b=True, act=8, aux=d8), dx8.float(), 1e-6, "8-bit image across kernels")
     finally:
         ops.set_gemm_variant(0)
     with pytest.raises(RuntimeError, match="act 5"):

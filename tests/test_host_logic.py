@@ -344,7 +344,7 @@ def test_ping_pong_gemm_kernels_spill_nothing_outside_the_saved_derivative_epilo
     spec.loader.exec_module(kr)
     if not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
         pytest.skip("no llvm-readelf in this image")
-    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    seen = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0}        # (4 / 5: the 8-bit derivative image of round 4 - forward like 2, backward like 3)
     for obj in ("gemm.o", "gemm_h16.o"):
         path = os.path.join(REPO, "simseg_amd", "build", obj)
         if not os.path.exists(path):
@@ -357,7 +357,7 @@ def test_ping_pong_gemm_kernels_spill_nothing_outside_the_saved_derivative_epilo
             ek = int([a or b for a, b in args][-1])                       # the last integer template argument: the epilogue kind
             is16 = "float" not in name.split("kernel")[1][:12] and not re.search(r"kernelIf", name)
             seen[ek] += 1
-            if not is16 or ek in (0, 2):
+            if not is16 or ek in (0, 2, 4):
                 assert spill == 0 and scratch == 0, (obj, name, vgpr, spill, scratch)
             else:
                 assert spill <= 48 and scratch <= 200, (obj, name, vgpr, spill, scratch)
