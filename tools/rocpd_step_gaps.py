@@ -13,6 +13,9 @@ def main(path, min_us=20.0):
     sym = next(t for t in tables if t.startswith("rocpd_info_kernel_symbol"))
     rows = list(c.execute(f"select d.start, d.end, s.kernel_name from {disp} d join {sym} s on d.kernel_id = s.id order by d.start"))
     adam = [i for i, r in enumerate(rows) if "adamw" in r[2]]
+    # (round 4: the text tower's parameters are updated by a launch of their own on the text tower's stream - a step's optimizer launches
+    #  lie within a few ms of each other; the LAST of such a group delimits the step)
+    adam = [i for k, i in enumerate(adam) if k + 1 == len(adam) or rows[adam[k + 1]][0] - rows[i][1] > 20e6]
     if len(adam) < 3:
         print("fewer than three optimizer launches in the trace"); return
     # the step to show: the SHORTEST interval between two consecutive optimizer launches (bench.py runs further legs after the timed
