@@ -14,8 +14,12 @@ def main(path, min_us=20.0):
     rows = list(c.execute(f"select d.start, d.end, s.kernel_name from {disp} d join {sym} s on d.kernel_id = s.id order by d.start"))
     adam = [i for i, r in enumerate(rows) if "adamw" in r[2]]
     # (round 4: the text tower's parameters are updated by a launch of their own on the text tower's stream - a step's optimizer launches
-    #  lie within a few ms of each other; the LAST of such a group delimits the step)
-    adam = [i for k, i in enumerate(adam) if k + 1 == len(adam) or rows[adam[k + 1]][0] - rows[i][1] > 20e6]
+    #  lie within a fraction of a step of each other (the text tower finishes ~20 ms before the image tower at 512 pairs); the LAST of such a
+    #  group delimits the step.  Group = launches closer than 0.4 of the median distance between every second launch.
+    if len(adam) > 4:
+        two = sorted(rows[adam[k + 2]][0] - rows[adam[k]][0] for k in range(len(adam) - 2))
+        lim = 0.4 * two[len(two) // 2]
+        adam = [i for k, i in enumerate(adam) if k + 1 == len(adam) or rows[adam[k + 1]][0] - rows[i][1] > lim]
     if len(adam) < 3:
         print("fewer than three optimizer launches in the trace"); return
     # the step to show: the SHORTEST interval between two consecutive optimizer launches (bench.py runs further legs after the timed
