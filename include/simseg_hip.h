@@ -76,10 +76,12 @@ int simseg_gemm_last_variant(void);
  * (eps 1e-6) and HF Bert*Output.LayerNorm / BertEmbeddings.LayerNorm (eps 1e-12). */
 int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_dtype, void* y_bf16,
                          float* mean, float* rstd, int64_t rows, int64_t D, float eps, void* stream);
-/* dx = LN'(dy_bf16 + dy_f32) + dres; writes dx_f32 and/or dx_bf16 (the bf16 copy optionally with the dropout mask
+/* dx = LN'(dy_bf16 + dy_f32) + dres + dres_bf16; writes dx_f32 and/or dx_bf16 (the bf16 copy optionally with the dropout mask
  * (drop_seed, drop_p) of the producing dense layer re-applied); dgamma/dbeta and dxsum (column sums of dx_bf16's values,
- * optional) are ACCUMULATED. */
-int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x, const float* mean,
+ * optional) are ACCUMULATED.  dres_bf16 (round 4, optional): the residual-stream gradient as the 16-bit copy the previous
+ * call wrote - in the 16-bit training modes the ViT blocks hand it from LayerNorm backward to LayerNorm backward in that form
+ * and no fp32 image of it is written (dx_f32 = NULL): every GEMM that consumes it reads 16-bit operands anyway. */
+int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const void* dres_bf16, const float* x, const float* mean,
                          const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
                          float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p,
                          void* stream);

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // bias gradient of that dense layer) are accumulated with one atomic per column per block.
 template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
-                                                     const float* __restrict__ dres, const float* __restrict__ x,
+                                                     const float* __restrict__ dres, const bf16_t* __restrict__ dres16,
+                                                     const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx32,
                                                      bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
@@ -134,6 +135,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
                 load4_nt(x + o, xv);
                 if (dres) load4_nt(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
+                if (dres16) {                              // the residual gradient as the previous kernel's 16-bit copy (round 4: half the bytes)
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dres16 + o));
+                    rr[i][0] += (float)t[0]; rr[i][1] += (float)t[1]; rr[i][2] += (float)t[2]; rr[i][3] += (float)t[3];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -649,12 +654,12 @@ extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const fl
     return 0;
 }
 
-extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const float* x,
+extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const void* dres_bf16, const float* x,
                                     const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
                                     float* dgamma, float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D,
                                     uint64_t drop_seed, float drop_p, void* stream) {
-    SS_HALF_FWD(simseg_layernorm_bwd, dy_bf16, dy_f32, dres, x, mean, rstd, gamma, dx_f32, dx_bf16, dgamma, dbeta, dxsum, partials, rows, D, drop_seed, drop_p, stream);
-    SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta, "layernorm_bwd: null pointer");
+    SS_HALF_FWD(simseg_layernorm_bwd, dy_bf16, dy_f32, dres, dres_bf16, x, mean, rstd, gamma, dx_f32, dx_bf16, dgamma, dbeta, dxsum, partials, rows, D, drop_seed, drop_p, stream);
+    SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
     if (rows <= 0) return 0;
@@ -663,7 +668,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int nc = (int)((D + 255) / 256);
 #define LN_BWD_LAUNCH(C)                                                                                                              \
-    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, x, mean, rstd, gamma, \
+    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, (const bf16_t*)dres_bf16, x, mean, rstd, gamma, \
                        dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
     if (nc <= 1) LN_BWD_LAUNCH(1);
     else if (nc == 2) LN_BWD_LAUNCH(2);

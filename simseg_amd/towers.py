@@ -186,6 +186,27 @@ def _zeros(device, *shapes):
 # 2.5e-3, the product's own rounding to 16 bits being 1.7e-3 (tests/test_gpu_kernels.py).  SIMSEG_AMD_GELU_GRAD_BITS=16: the
 # 16-bit image.
 _GELU8 = os.environ.get("SIMSEG_AMD_GELU_GRAD_BITS", "8") != "16"
+# The gradient of the ViT residual stream between the LayerNorm backward kernels of the 16-bit training modes: handed on as the 16-bit copy
+# each kernel writes anyway (every GEMM that consumes it reads 16-bit operands), no fp32 image written or read - 0.93 GB per ViT-B layer and
+# step less.  Measured on every parameter gradient against the exact-fp32 backward (ViT-B + BERT-base, B = 256): mean 1 - cosine 5.06e-4
+# against 5.04e-4 with the fp32 stream (tests/test_gpu_fullsize.py).  The fp32 tensor autograd passes from block to block is then an
+# UNWRITTEN allocation marked `_simseg_lazy32`; only this module's functions produce and consume it (vit_forward's chain), and a consumer
+# that finds the mark without a valid 16-bit shadow refuses loudly.  SIMSEG_AMD_RESGRAD_BITS=32: the fp32 stream.
+_RES16 = os.environ.get("SIMSEG_AMD_RESGRAD_BITS", "16") != "32"
+
+
+def _lazy32(shape, device, dx16, dsum):
+    """The fp32 gradient tensor autograd wants, NOT written: its values live in the 16-bit shadow only."""
+    dx = torch.empty(shape, device=device, dtype=F32)
+    dx._simseg_lazy32 = True
+    _put_shadow(dx, dx16.view(shape), dsum)
+    return dx
+
+
+def _need_shadow(t32, sh):
+    if sh is None and getattr(t32, "_simseg_lazy32", False):
+        raise RuntimeError("a residual-stream gradient that exists only as its 16-bit shadow (SIMSEG_AMD_RESGRAD_BITS=16) reached a consumer without a "
+                           "valid shadow - was it modified in place, or consumed twice?  Set SIMSEG_AMD_RESGRAD_BITS=32")
 
 
 def _grad_target(p):
@@ -294,12 +315,14 @@ def _act_grad(t32, adt):
     return t32 if adt == F32 else ops.cast(t32, adt)
 
 
-def _ln_bwd(adt, x, mean, rstd, w, dg, db, dy, dres=None, dy32=None, dxsum=None, drop=(0.0, 0)):
+def _ln_bwd(adt, x, mean, rstd, w, dg, db, dy, dres=None, dy32=None, dxsum=None, drop=(0.0, 0), dres16=None, want32=True):
     """Backward of a LayerNorm whose input was `x`: dx = LN'(dy [+ dy32]) + dres.  Returns (dx fp32, dx in the compute dtype with the
     dropout mask `drop` = (p, seed) of the dense layer that produced x re-applied); column sums of the second go to dxsum (that
     layer's bias gradient).  In bf16 mode all of it is one kernel; in exact mode the pieces are separate launches."""
     if adt != F32:
-        return ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dy32=dy32, dres=dres, dxsum=dxsum, drop_seed=drop[1], drop_p=drop[0], want_bf16=adt)
+        # (dres16 / want32=False: the residual-stream gradient arrives as - and leaves only as - the 16-bit copy, see _RES16)
+        return ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dy32=dy32, dres=dres, dres16=dres16, dxsum=dxsum, drop_seed=drop[1], drop_p=drop[0],
+                                 want_bf16=adt, want_f32=want32)
     if dy32 is not None:
         raise ValueError("exact mode: fold the second gradient into `dy` with the producing GEMM's residual epilogue")
     dx32, _ = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy, dres=dres, want_bf16=False)
@@ -366,13 +389,15 @@ class LinearFn(_GradAwareFn):
 
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, w, b, eps, adt=None):
+    def forward(ctx, x, w, b, eps, adt=None, lazy_ok=False):
         x = x.contiguous()
         # (adt = a 16-bit compute type: the kernel writes a copy of y in it next to the fp32 rows, picked up by the consumer - ProjectPoolFn
         #  through y._simseg_fwd16 - instead of a cast pass over the features)
         y, y16, mean, rstd = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, save_stats=True, want_bf16_copy=adt if adt in ops.HALF_TYPES else False)
         if y16 is not None:
             y._simseg_fwd16 = (y16, y._version)
+        ctx.lazy = adt in ops.HALF_TYPES and _RES16 and lazy_ok
+        ctx.adt16 = adt if adt in ops.HALF_TYPES else True          # (the shadow's type: the consumer accepts only its own compute type)
         ctx.save_for_backward(x, mean, rstd, w.detach())
         return y
 
@@ -380,9 +405,12 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         x, mean, rstd, w = ctx.saved_tensors
         dg, db, dsum = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
-        dx, dx16 = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), dxsum=dsum)
-        _put_shadow(dx, dx16, dsum)
-        return dx, dg, db, None, None
+        dx, dx16 = ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy32=dy.contiguous(), dxsum=dsum, want_f32=not ctx.lazy, want_bf16=ctx.adt16)
+        if dx is None:       # (lazy_ok: the producer of x is a ViTBlockFn, which reads the shadow only)
+            dx = _lazy32(x.shape, x.device, dx16, dsum)
+        else:
+            _put_shadow(dx, dx16, dsum)
+        return dx, dg, db, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -414,20 +442,26 @@ class ViTEmbedFn(_GradAwareFn):
         B, N, D = ctx.dims
         dx = dx.contiguous()
         sh = _take_shadow(dx, ctx.adt) if ctx.adt != F32 else None
+        _need_shadow(dx, sh)
+        lazy = getattr(dx, "_simseg_lazy32", False)
         if sh is not None:       # the first block's backward left a 16-bit copy of dx: slice THAT (half the bytes of the fp32 slice, no cast pass; same bits)
-            dp16 = sh[0].view(B, N + 1, D)[:, 1:].contiguous().view(-1, D)
+            dx16 = sh[0].view(B, N + 1, D)
+            dp16 = dx16[:, 1:].contiguous().view(-1, D)
         else:
             dp16 = _act_grad(dx[:, 1:].contiguous().view(-1, D), ctx.adt)
         dw = _wgrad(dp16, cols).view(D, 3, 16, 16) if ctx.needs_input_grad[1] else None
         db = _bgrad(dp16) if ctx.needs_input_grad[2] else None
         dcls = dpos = None
         if ctx.needs_input_grad[3]:
-            dcls = torch.zeros(D, device=dx.device, dtype=F32)
-            ops.vit_cls_grad(dx, dcls)
-            dcls = dcls.view(1, 1, D)
+            if lazy:             # (the fp32 image of dx was never written: the [cls] rows of its 16-bit shadow)
+                dcls = dx16[:, 0].float().sum(0).view(1, 1, D)
+            else:
+                dcls = torch.zeros(D, device=dx.device, dtype=F32)
+                ops.vit_cls_grad(dx, dcls)
+                dcls = dcls.view(1, 1, D)
         if ctx.needs_input_grad[4]:
             dpos = torch.zeros((N + 1) * D, device=dx.device, dtype=F32)
-            ops.colsum_accum(dx.view(B, (N + 1) * D), dpos)
+            ops.colsum_accum((dx16 if lazy else dx).view(B, (N + 1) * D), dpos)
             dpos = dpos.view(1, N + 1, D)
         return None, dw, db, dcls, dpos, None
 
@@ -436,7 +470,9 @@ class ViTBlockFn(_GradAwareFn):
     """timm Block: x + proj(attn(norm1 x)); then + fc2(gelu(fc1(norm2 .)))   (pre-LN, eps 1e-6, erf GELU)."""
 
     @staticmethod
-    def forward(ctx, x, heads, adt, n1w, n1b, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, heads, adt, n1w, n1b, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, lazy_ok=False):
+        # lazy_ok: the producer of x is another function of this module that reads the 16-bit shadow of the gradient returned here and
+        # never its fp32 values (vit_forward's chain) - see _RES16
         B, T, D = x.shape
         x = x.contiguous()
         save = _saving(ctx)
@@ -468,6 +504,7 @@ class ViTBlockFn(_GradAwareFn):
         act = ops.gemm(ln2, f1w_, bias=f1b.detach(), act=((7 if g8 else 5) if blk else 3) if save else 1, aux_out=pre)     # pre holds GELU'(fc1 output)
         y = ops.gemm(act, f2w_, bias=f2b.detach(), residual=x1, out_dtype=F32)
         ctx.adt, ctx.heads, ctx.dims, ctx.blk = adt, heads, (B, T, D), (2 if g8 else 1) if blk else 0
+        ctx.lazy = bool(lazy_ok) and adt != F32 and _RES16
         ctx.wparams = (f2w, f1w, pw, qw)                                  # (the parameter objects: _grad_target in the backward)
         if save:
             ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act, qw_, pw_, f1w_, f2w_,
@@ -483,6 +520,8 @@ class ViTBlockFn(_GradAwareFn):
         need = ctx.needs_input_grad
         dy = dy.contiguous()
         sh = _take_shadow(dy, adt) if adt != F32 else None
+        _need_shadow(dy, sh)
+        res16 = sh is not None and adt != F32 and _RES16      # the residual gradient is taken from its 16-bit shadow (the fp32 image may not even exist)
         dy = dy.view(-1, D)
         if sh is not None:
             dy16, df2b = sh[0].view(-1, D), sh[1]
@@ -498,7 +537,9 @@ class ViTBlockFn(_GradAwareFn):
         df2w = _wgrad(dy16, act, df2w_z) if need[13] else None
         dln2 = _dgrad(dpre, f1w_)
         df1w = _wgrad(dpre, ln2, df1w_z) if need[11] else None
-        dx1_32, dx1_16 = _ln_bwd(adt, x1, mean2, rstd2, n2w, dn2w, dn2b, dln2, dres=dy, dxsum=dpb)
+        r16 = adt != F32 and _RES16                           # between this block's two LayerNorm backward kernels: 16 bits only
+        dx1_32, dx1_16 = _ln_bwd(adt, x1, mean2, rstd2, n2w, dn2w, dn2b, dln2, dres=None if res16 else dy, dres16=dy16 if res16 else None, dxsum=dpb,
+                                 want32=not r16)
         # attention
         datt = _dgrad(dx1_16, pw_)
         dpw = _wgrad(dx1_16, att.view(-1, D), dpw_z) if need[7] else None
@@ -509,11 +550,15 @@ class ViTBlockFn(_GradAwareFn):
             ops.colsum_accum(dqkv, dqb)
         dln1 = _dgrad(dqkv, qw_)
         dqw = _wgrad(dqkv, ln1.view(-1, D), dqw_z) if need[5] else None
-        dx, dx16 = _ln_bwd(adt, x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dln1, dres=dx1_32, dxsum=dsum)
-        dx = dx.view(B, T, D)
-        if adt != F32:
-            _put_shadow(dx, dx16, dsum)
-        return (dx, None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b)
+        dx, dx16 = _ln_bwd(adt, x.view(-1, D), mean1, rstd1, n1w, dn1w, dn1b, dln1, dres=None if r16 else dx1_32, dres16=dx1_16 if r16 else None,
+                           dxsum=dsum, want32=not ctx.lazy)
+        if dx is None:
+            dx = _lazy32((B, T, D), x.device, dx16, dsum)
+        else:
+            dx = dx.view(B, T, D)
+            if adt != F32:
+                _put_shadow(dx, dx16, dsum)
+        return (dx, None, None, dn1w, dn1b, dqw, dqb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None)
 
 
 def vit_forward(m, image, adt):
@@ -522,8 +567,8 @@ def vit_forward(m, image, adt):
     for blk in m.blocks:
         x = ViTBlockFn.apply(x, m.num_heads, adt, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
                              blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
-                             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-    return LayerNormFn.apply(x, m.norm.weight, m.norm.bias, 1e-6, adt)
+                             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)      # (lazy_ok: the chain below)
+    return LayerNormFn.apply(x, m.norm.weight, m.norm.bias, 1e-6, adt, True)
 
 
 # ------------------------------------------------------------------------------------------------------------------
