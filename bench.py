@@ -728,9 +728,9 @@ def main():
     # 5.04e-4).  Secondary figure, same process.
     gelu16 = None
     from simseg_amd import towers as _tw
-    compact0 = (_tw._GELU8, _tw._RES16)
-    if (compact0[0] or compact0[1]) and os.environ.get("SIMSEG_BENCH_GELU16_LEG", "1") != "0":
-        _tw._GELU8 = _tw._RES16 = False
+    compact0 = (_tw._GELU8, _tw._RES16, _tw._XHAT_Y)
+    if any(compact0) and os.environ.get("SIMSEG_BENCH_GELU16_LEG", "1") != "0":
+        _tw._GELU8 = _tw._RES16 = _tw._XHAT_Y = False
         try:
             for _ in range(2):
                 step()
@@ -748,7 +748,7 @@ def main():
                 dist.all_reduce(el4, op=dist.ReduceOp.MAX)
             gelu16 = {"pairs_per_s": round(world * B * args.steps / float(el4), 2), "ms_per_step": round(1e3 * float(el4) / args.steps, 3)}
         finally:
-            _tw._GELU8, _tw._RES16 = compact0
+            _tw._GELU8, _tw._RES16, _tw._XHAT_Y = compact0
 
     # ---- the same step in the reference's own AMP type: fp16 compute + a live GradScaler (clip_runner.py:226-230, core/hooks/
     # optimizer.py:73-82) - the fp16 flavour of the same kernels (secondary figure, same process; single-rank runs only: the scaler's
@@ -946,12 +946,13 @@ def main():
                            "gemm_time_share_single_stream": round(gemm_sec / (elapsed / args.steps), 3),
                            "gemm_breakdown_ms": {k: round(1e3 * v[2], 3) for k, v in sorted(agg.items())},
                            "final_loss": round(float(loss.detach()), 4),
-                           "with_padded_caption_tokens_computed": dense_text, "with_16bit_gelu_image_and_fp32_residual_gradient": gelu16,
+                           "with_padded_caption_tokens_computed": dense_text, "with_round3_forms_of_the_backward_streams": gelu16,
                            "backward_streams": {"gelu_derivative_image": ("8-bit (simseg_gemm act 7 / 8: uniform grid over GELU''s range; the product it feeds is as "
                                                                           "accurate as with the 16-bit image)" if _tw._GELU8 else "16-bit"),
                                                 "vit_residual_gradient_between_layernorm_backwards": "16-bit copies only" if _tw._RES16 else "fp32 image",
-                                                "fidelity": "mean 1 - cosine of every parameter gradient to the exact-fp32 backward, ViT-B + BERT-base, B = 256: 5.06e-4 "
-                                                            "(both compact forms) vs 5.04e-4 (round-3 forms): tests/test_gpu_fullsize.py"},
+                                                "vit_layernorm_backward_normalised_value": "from the saved 16-bit output where the gains allow it" if _tw._XHAT_Y else "from the fp32 input",
+                                                "fidelity": "mean 1 - cosine of every parameter gradient to the exact-fp32 backward, ViT-B + BERT-base, B = 256: 4.64e-4 "
+                                                            "(all compact forms) vs 4.63e-4 (round-3 forms): tests/test_gpu_fullsize.py"},
                            "fp16_amp_with_gradscaler": fp16_amp},
             "seg_eval": seg,
             "retrieval_eval": retr,

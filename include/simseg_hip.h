@@ -80,8 +80,12 @@ int simseg_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
  * (drop_seed, drop_p) of the producing dense layer re-applied); dgamma/dbeta and dxsum (column sums of dx_bf16's values,
  * optional) are ACCUMULATED.  dres_bf16 (round 4, optional): the residual-stream gradient as the 16-bit copy the previous
  * call wrote - in the 16-bit training modes the ViT blocks hand it from LayerNorm backward to LayerNorm backward in that form
- * and no fp32 image of it is written (dx_f32 = NULL): every GEMM that consumes it reads 16-bit operands anyway. */
-int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const void* dres_bf16, const float* x, const float* mean,
+ * and no fp32 image of it is written (dx_f32 = NULL): every GEMM that consumes it reads 16-bit operands anyway.
+ * y_bf16 + beta (round 4, optional): the layer's saved 16-bit OUTPUT y = xhat * gamma + beta; the normalised value xhat is then taken from it
+ * ((y - beta) / gamma) instead of from the fp32 input x for every 4-channel chunk with |gamma| >= 0.05 and |beta| <= 4 |gamma| (half the bytes
+ * of the kernel's largest read); the other chunks - and everything when y_bf16 is NULL - read x, which must always be given. */
+int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const void* dres_bf16, const float* x,
+                         const void* y_bf16, const float* beta, const float* mean,
                          const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16, float* dgamma,
                          float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D, uint64_t drop_seed, float drop_p,
                          void* stream);

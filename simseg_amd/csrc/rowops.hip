@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
                                                      const float* __restrict__ dres, const bf16_t* __restrict__ dres16,
-                                                     const float* __restrict__ x,
+                                                     const float* __restrict__ x, const bf16_t* __restrict__ y16, const float* __restrict__ beta,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx32,
                                                      bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
@@ -109,12 +109,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     float ag[MAXC][4], ab[MAXC][4], as[MAXC][4], gm[MAXC][4];
+    // y16 (round 4): the normalised value xhat = (x - mean) * rstd is taken from the layer's saved 16-bit OUTPUT y = xhat * gamma + beta instead of
+    // its fp32 input - half the bytes of the kernel's largest read - for every 4-channel chunk whose gains allow it (|gamma| >= 0.05 and
+    // |beta| <= 4 |gamma|: the 16-bit rounding of y then perturbs xhat by <= 1 %); the other chunks read x as before, exactly.
+    float ig[MAXC][4], bt[MAXC][4];
+    bool fromy[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; gm[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; gm[i][j] = 0.f; ig[i][j] = 0.f; bt[i][j] = 0.f; }
         const int c = lane + 64 * i;
-        if (c < nch) load4<float>(gamma + c * 4, gm[i]);
+        fromy[i] = false;
+        if (c < nch) {
+            load4<float>(gamma + c * 4, gm[i]);
+            if (y16) {
+                load4<float>(beta + c * 4, bt[i]);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ok = ok && fabsf(gm[i][j]) >= 0.05f && fabsf(bt[i][j]) <= 4.f * fabsf(gm[i][j]); ig[i][j] = 1.0f / gm[i][j]; }
+                fromy[i] = ok;
+            }
+        }
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -133,7 +148,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3];
                 }
                 if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
-                load4_nt(x + o, xv);
+                if (fromy[i]) {
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(y16 + o));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[j] = ((float)t[j] - bt[i][j]) * ig[i][j];       // = xhat
+                } else {
+                    load4_nt(x + o, xv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[j] = (xv[j] - mu) * rs;
+                }
                 if (dres) load4_nt(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
                 if (dres16) {                              // the residual gradient as the previous kernel's 16-bit copy (round 4: half the bytes)
                     const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dres16 + o));
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xh[i][j] = (xv[j] - mu) * rs;
+                    xh[i][j] = xv[j];
                     ag[i][j] += a[j] * xh[i][j];
                     ab[i][j] += a[j];
                     g[i][j] = a[j] * gm[i][j];
@@ -655,11 +678,12 @@ extern "C" int simseg_layernorm_fwd(const float* x, const float* gamma, const fl
 }
 
 extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* dres, const void* dres_bf16, const float* x,
+                                    const void* y_bf16, const float* beta,
                                     const float* mean, const float* rstd, const float* gamma, float* dx_f32, void* dx_bf16,
                                     float* dgamma, float* dbeta, float* dxsum, float* partials, int64_t rows, int64_t D,
                                     uint64_t drop_seed, float drop_p, void* stream) {
-    SS_HALF_FWD(simseg_layernorm_bwd, dy_bf16, dy_f32, dres, dres_bf16, x, mean, rstd, gamma, dx_f32, dx_bf16, dgamma, dbeta, dxsum, partials, rows, D, drop_seed, drop_p, stream);
-    SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
+    SS_HALF_FWD(simseg_layernorm_bwd, dy_bf16, dy_f32, dres, dres_bf16, x, y_bf16, beta, mean, rstd, gamma, dx_f32, dx_bf16, dgamma, dbeta, dxsum, partials, rows, D, drop_seed, drop_p, stream);
+    SS_CHECK((dy_bf16 || dy_f32) && x && mean && rstd && gamma && dgamma && dbeta && (dx_f32 || dx_bf16) && (!y_bf16 || beta), "layernorm_bwd: null pointer");
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
     if (rows <= 0) return 0;
@@ -668,7 +692,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int nc = (int)((D + 255) / 256);
 #define LN_BWD_LAUNCH(C)                                                                                                              \
-    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, (const bf16_t*)dres_bf16, x, mean, rstd, gamma, \
+    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, (const bf16_t*)dres_bf16, x, (const bf16_t*)y_bf16, beta, mean, rstd, gamma, \
                        dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
     if (nc <= 1) LN_BWD_LAUNCH(1);
     else if (nc == 2) LN_BWD_LAUNCH(2);

@@ -121,7 +121,7 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, want_bf16_copy=F
 
 
 def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dres=None, want_f32=True, want_bf16=True,
-                  dxsum=None, drop_seed=0, drop_p=0.0, dres16=None):
+                  dxsum=None, drop_seed=0, drop_p=0.0, dres16=None, y16=None, beta=None):
     require_gpu(x)
     D = x.shape[-1]
     rows = x.numel() // D
@@ -129,7 +129,8 @@ def layernorm_bwd(x, mean, rstd, gamma, dgamma, dbeta, dy16=None, dy32=None, dre
     h16 = dy16.dtype if dy16 is not None else (want_bf16 if isinstance(want_bf16, torch.dtype) else torch.bfloat16)
     dx16 = torch.empty(x.shape, device=x.device, dtype=h16) if want_bf16 else None
     partials = torch.empty(raw("simseg_layernorm_bwd_workspace_bytes", rows, D) // 4, device=x.device, dtype=torch.float32)
-    call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(dres16)), ptr(_c(x)), ptr(mean), ptr(rstd), ptr(gamma),
+    call("simseg_layernorm_bwd", ptr(_c(dy16)), ptr(_c(dy32)), ptr(_c(dres)), ptr(_c(dres16)), ptr(_c(x)), ptr(_c(y16)), ptr(_c(beta)) if y16 is not None else None,
+         ptr(mean), ptr(rstd), ptr(gamma),
          ptr(dx32), ptr(dx16), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(partials), rows, D, int(drop_seed), float(drop_p), stream())
     return dx32, dx16
 

@@ -249,9 +249,10 @@ def test_vitb_512_window_forward_vs_oracle(monkeypatch):
 
 
 def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
-    """Round 4 halves two streams of the 16-bit training step: the MLP blocks save GELU' as an 8-bit tile-blocked image (simseg_gemm act 7 / 8)
-    instead of a 16-bit one (act 5 / 6), and the ViT blocks hand the residual-stream gradient from LayerNorm backward to LayerNorm backward
-    as the 16-bit copy those kernels write anyway instead of an fp32 image (simseg_layernorm_bwd dres_bf16; towers._RES16).  At a batch whose
+    """Round 4 halves three streams of the 16-bit training step: the MLP blocks save GELU' as an 8-bit tile-blocked image (simseg_gemm act 7 / 8)
+    instead of a 16-bit one (act 5 / 6), the ViT blocks hand the residual-stream gradient from LayerNorm backward to LayerNorm backward
+    as the 16-bit copy those kernels write anyway instead of an fp32 image (simseg_layernorm_bwd dres_bf16; towers._RES16), and those kernels
+    take the normalised value from the layer's saved 16-bit output instead of its fp32 input (y_bf16; towers._XHAT_Y).  At a batch whose
     GEMMs take the blocked path (B = 256: 50 432 image rows = 197 full tiles), ViT-B/16 + BERT-base: every parameter gradient of the bf16
     step stays as close to the exact-fp32 gradient (the same hand-written backward in fp32 arithmetic, same weights, same batch) as with
     the round-3 forms - per tensor and on average."""
@@ -261,6 +262,15 @@ def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
     assert ops.gemm_aux_blocked_ok(B * 197, 3072, 768)
     torch.manual_seed(5)
     m = _build_vitb(224).cuda().eval()
+    # LayerNorm parameters of the image tower as a trained model has them (gains spread over a decade, some small; offsets of the gains' order):
+    # the third compact form below takes the normalised value from the saved 16-bit LayerNorm output, (y - beta) / gamma
+    gg = torch.Generator(device="cuda").manual_seed(9)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "image_encoder" in n and "norm" in n and n.endswith("weight"):
+                p.copy_(torch.exp(torch.randn(p.shape, device="cuda", generator=gg) * 0.7).clamp(0.03, 4.0))
+            if "image_encoder" in n and "norm" in n and n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, device="cuda", generator=gg) * 0.3)
     image = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(31)).cuda()
     ids, mask = R.synthetic_text(B, L, 30522, seed=32, min_len=8)
     batch = {"image": image, "input_ids": ids.cuda(), "attention_mask": mask.cuda()}
@@ -270,10 +280,12 @@ def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
     monkeypatch.setattr(ops, "gemm", lambda *a, **k: (calls.append(k.get("act", 0)), real_gemm(*a, **k))[1])
     monkeypatch.setattr(ops, "layernorm_bwd", lambda *a, **k: (lnb.append((k.get("dres16") is not None, k.get("want_f32", True))), real_lnb(*a, **k))[1])
     grads, losses = {}, {}
-    for tag, mode, g8, r16 in (("fp32", "fp32", False, False), ("r3", "bf16", False, False), ("g8", "bf16", True, False), ("g8r16", "bf16", True, True)):
+    for tag, mode, g8, r16, xy in (("fp32", "fp32", False, False, False), ("r3", "bf16", False, False, False), ("g8", "bf16", True, False, False),
+                                   ("g8r16", "bf16", True, True, False), ("g8r16y", "bf16", True, True, True)):
         monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
         monkeypatch.setattr(towers, "_GELU8", g8)
         monkeypatch.setattr(towers, "_RES16", r16)
+        monkeypatch.setattr(towers, "_XHAT_Y", xy)
         calls.clear(); lnb.clear()
         m.zero_grad(set_to_none=True)
         loss = m(batch)[0]["nce_loss"]
@@ -284,13 +296,15 @@ def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
         if tag == "r3":
             assert calls.count(5) == 24 and calls.count(6) == 24 and 7 not in calls, sorted(set(calls))
             assert not any(a for a, _ in lnb)
-        if tag in ("g8", "g8r16"):
+        if tag == "g8r16y":
+            assert sum(1 for a, _ in lnb if a) == 24      # (the same 24 calls; they now carry y16 / beta - checked at the kernel level)
+        if tag in ("g8", "g8r16", "g8r16y"):
             assert calls.count(7) == 24 and calls.count(8) == 24 and 5 not in calls, sorted(set(calls))      # every MLP block of both towers
-        if tag == "g8r16":       # the 24 LayerNorm backward calls of the ViT blocks take the 16-bit residual gradient; 24 + the final norm write no fp32 image
+        if tag in ("g8r16", "g8r16y"):       # the 24 LayerNorm backward calls of the ViT blocks take the 16-bit residual gradient; 24 + the final norm write no fp32 image
             assert sum(a for a, _ in lnb) == 24 and sum(not w for _, w in lnb) == 25, lnb
-    assert abs(losses["g8r16"] - losses["r3"]) < 1e-6 * abs(losses["r3"]) + 1e-7      # the forward does not change
+    assert abs(losses["g8r16y"] - losses["r3"]) < 1e-6 * abs(losses["r3"]) + 1e-7      # the forward does not change
     base = {n: 1 - _cos(grads["r3"][n], g) for n, g in grads["fp32"].items() if float(g.norm()) >= 1e-6}
-    for tag in ("g8", "g8r16"):
+    for tag in ("g8", "g8r16", "g8r16y"):
         d = {n: 1 - _cos(grads[tag][n], grads["fp32"][n]) for n in base}
         worse = [(n, base[n], d[n]) for n in base if d[n] > 1.25 * base[n] + 2e-4]
         print(f"1 - cosine to the exact-fp32 gradient, mean over {len(base)} tensors: round-3 forms {np.mean(list(base.values())):.4e}, {tag} {np.mean(list(d.values())):.4e}; "

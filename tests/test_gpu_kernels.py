@@ -348,6 +348,37 @@ def test_layernorm_fwd_bwd(ops, D):
     _close(dsum, (dx32 * keep).sum(0), 1e-4, "ln bwd column sums")
 
 
+@pytest.mark.parametrize("D", [384, 768])
+def test_layernorm_bwd_16bit_residual_and_xhat_from_the_saved_output(ops, D):
+    """Round 4 inputs of simseg_layernorm_bwd: the residual gradient as a 16-bit tensor (dres_bf16, no fp32 image out) and the normalised value
+    taken from the layer's saved 16-bit OUTPUT (y_bf16 + beta) instead of the fp32 input - for the chunks whose gains allow it; chunks with a
+    small gain or a large offset read x as before.  Against the fp64 derivative."""
+    rows = 517
+    x = _rand(rows, D, seed=1, scale=3.0) + 0.5
+    g, b = torch.exp(_rand(D, seed=2) * 0.7), _rand(D, seed=3) * 0.3
+    g[5] = 0.01; g[40] = -0.02; b[77] = 9.0; g[77] = 1.0          # chunks that must fall back to x (tiny gain, offset >> gain)
+    y, y16, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, want_bf16_copy=True, save_stats=True)
+    dy16, dres16 = _rand(rows, D, seed=5, dtype=torch.bfloat16), _rand(rows, D, seed=6, dtype=torch.bfloat16)
+    xr = x.double().requires_grad_(True); gr = g.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy16.double())
+    want = xr.grad + dres16.double()
+    res = {}
+    for tag, kw in (("x", {}), ("y", dict(y16=y16, beta=b))):
+        dgam = torch.zeros(D, device="cuda"); dbet = torch.zeros(D, device="cuda")
+        dx32, dx16 = ops.layernorm_bwd(x, mean, rstd, g, dgam, dbet, dy16=dy16, dres16=dres16, want_f32=False, **kw)
+        assert dx32 is None
+        res[tag] = (dx16.double(), dgam.double(), dbet.double())
+    rel = lambda a, w: float((a - w).norm() / w.norm())       # noqa: E731
+    ex, ey = rel(res["x"][0], want), rel(res["y"][0], want)
+    assert ex < 3e-3 and ey < 1.3 * ex + 2e-4, (ex, ey)        # the 16-bit rounding of dx dominates both
+    _close(res["y"][1], gr.grad, 5e-3, "dgamma with xhat from y")
+    _close(res["y"][2], br.grad, 1e-4, "dbeta")
+    # the fall-back chunks read x like the x path (their rows' two reductions still see the other chunks' xhat from y: close, not bit-equal)
+    for c in (5, 40, 77):
+        lo = c // 4 * 4
+        assert float((res["x"][0][:, lo:lo + 4] - res["y"][0][:, lo:lo + 4]).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
 def test_colsum_transpose_cast(ops):
     x = _rand(1001, 776, seed=1)
     out = torch.ones(776, device="cuda")
