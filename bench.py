@@ -442,8 +442,8 @@ def retrieval_encode_bench(dev, n_img=5000, cap_per_img=5, img=288, L=25, ib=250
             "images_per_s": round(n_img / dt, 1), "captions_per_s": round(n_img * cap_per_img / dt, 1)}
 
 
-def attention_roofline(dev, B, img, L, H=12, reps=10):
-    """The bf16 attention kernels of the step, each timed alone (events, `reps` launches) on the step's own shapes: the image tower's
+def attention_roofline(dev, B, img, L, H=12, reps=10, dtype=torch.bfloat16):
+    """The 16-bit attention kernels of the step, each timed alone (events, `reps` launches) on the step's own shapes: the image tower's
     (B, T = 1 + (img/16)^2) and the text tower's (B, L) with dropout and a ragged key-padding mask.  FLOPs = 4 T^2 64 per head forward,
     2.5x that backward (five tile products against two); bytes = qkv read + ctx written (forward), + dO, O read and dqkv written (backward).
     Both fractions are given: at these lengths the kernels are bound by HBM traffic and softmax VALU work, not by the matrix pipe."""
@@ -463,7 +463,7 @@ def attention_roofline(dev, B, img, L, H=12, reps=10):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     for name, T, drop in (("attention_image_tower", 1 + (img // 16) ** 2, 0.0), ("attention_text_tower", L, 0.1)):
-        qkv = torch.randn(B, T, 3 * H * 64, device=dev, generator=g).bfloat16()
+        qkv = torch.randn(B, T, 3 * H * 64, device=dev, generator=g).to(dtype)
         mask, lens2 = None, float(T) * T * B
         if drop:
             lens = torch.randint(8, T + 1, (B,), device=dev, generator=g)
@@ -556,6 +556,31 @@ class ClockSampler:
                 "source": getattr(self, "source", None)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` - one rank per GPU over RCCL, rendezvous on 127.0.0.1 and a free port (the reference: launch.py:33-70 builds
+    `torch.distributed.launch --nproc_per_node`, simseg/core/initial.py:54 calls init_process_group from the environment).  The ranks inherit
+    stdout, so rank 0's one JSON line is still the only thing on it; the launcher's exit code is this process's."""
+    import socket
+    try:
+        have = torch.cuda.device_count()
+    except Exception:       # noqa: BLE001
+        have = 0
+    if have < n and "SIMSEG_BENCH_DEVICE" not in os.environ:
+        raise SystemExit(f"bench.py: --gpus {n} but {have} HIP device(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's intra-node transport fails with the legacy mode on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -569,13 +594,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seg", action="store_true", help="skip the zero-shot-seg eval stage measurement")
     ap.add_argument("--retrieval", action="store_true", help="with --no-seg: still run the (quick) retrieval metric legs")
+    ap.add_argument("--local_rank", "--local-rank", type=int, default=None,
+                    help="set by torch.distributed.launch-style launchers (the reference's launch.py:33-70); torch.distributed.run sets LOCAL_RANK instead")
     args = ap.parse_args()
 
-    os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                             # does not return: this process becomes the launcher of N ranks
+    HEAD = os.environ.get("SIMSEG_BENCH_HEADLINE", "fp16").lower()      # the headline step's arithmetic: the reference's own AMP type (fp16 +
+    assert HEAD in ("fp16", "bf16"), HEAD                               #  a live GradScaler, clip_runner.py:226-230); "bf16": round 1-4's headline
+    os.environ["SIMSEG_AMD_COMPUTE"] = HEAD
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("SIMSEG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", 0)))     # override: bring-up of N ranks on one GPU
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = int(os.environ.get("SIMSEG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", args.local_rank if args.local_rank is not None else 0)))     # override: bring-up of N ranks on one GPU
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with `python bench.py --gpus N`, which starts the N ranks "
+                         f"itself, or under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
     from simseg.utils import ENV, logger
     logger.STREAM = sys.stderr          # stdout carries the one JSON line only
     ENV.local_rank = local
@@ -631,7 +664,22 @@ def main():
             os.environ.setdefault("SIMSEG_AMD_TWO_STREAMS", "1")
         else:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=128)
-    opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3)
+    HALF = {"fp16": torch.float16, "bf16": torch.bfloat16}
+    opt = AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3, half_dtype=HALF[HEAD])
+    from simseg_amd.optim import GradScaler
+    # torch.amp.GradScaler (its defaults, as the reference constructs it: scale 65536, back-off 0.5, growth every 2000 clean steps) with this
+    # package's one-kernel overflow check; the skip decision stays on the device (no host read in the step).  With N > 1 ranks the check reads
+    # the EXCHANGED gradients (an inf on any rank is an inf in every rank's sum), so every rank takes the same decision.
+    scaler = GradScaler("cuda")
+    mode = [HEAD]
+
+    def set_mode(m):
+        """Arithmetic of the step: "fp16" (the reference's AMP: fp16 compute, scaled loss, live GradScaler) or "bf16" (no scaler)."""
+        if m != mode[0]:
+            mode[0] = m
+            os.environ["SIMSEG_AMD_COMPUTE"] = m
+            opt.half_dtype = HALF[m]          # the optimizer kernel's 16-bit weight copies follow the compute type
+            opt._plans.clear()
     # single process, two tower streams: the text tower's parameters are updated on the text tower's stream, i.e. as soon as ITS backward
     # has finished, beside the rest of the image tower's backward (SIMSEG_BENCH_OPT_STREAMS=0: one launch behind everything, as before)
     OPT_STREAMS = world == 1 and sync is None and os.environ.get("SIMSEG_BENCH_OPT_STREAMS", "1") != "0"
@@ -664,10 +712,16 @@ def main():
         if sync is not None and ZERO_COPY:
             sync.begin()                                                 # the large weight gradients are written straight into the exchange buffer
         loss_dict, _, _ = net(next_batch())
-        loss_dict["nce_loss"].backward()
+        amp = mode[0] == "fp16"
+        (scaler.scale(loss_dict["nce_loss"]) if amp else loss_dict["nce_loss"]).backward()
         if sync is not None:
             sync()
-        opt.step(grad_scale=sync.grad_scale if sync is not None else 1.0, param_streams=bool(getattr(model, "two_streams_used", False)))
+        kw = dict(grad_scale=sync.grad_scale if sync is not None else 1.0, param_streams=bool(getattr(model, "two_streams_used", False)))
+        if amp:
+            scaler.step(opt, **kw)       # overflow check (one read-only kernel) + AdamW with the unscale and the skip decision inside the kernel
+            scaler.update()
+        else:
+            opt.step(**kw)
         return loss_dict["nce_loss"]
 
     bdf = None
@@ -687,6 +741,7 @@ def main():
     torch.cuda.synchronize()
     if clocks is not None:
         clocks.mark()
+    taken0 = opt.steps_taken() if HEAD == "fp16" else 0        # (a host read, outside the timed region)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -699,6 +754,11 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
+    amp_info = None
+    if HEAD == "fp16":
+        amp_info = {"loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt.steps_taken() - taken0, "steps": args.steps,
+                    "note": "GradScaler live: scaled backward; overflow check = one read-only kernel, unscale + skip decision inside the AdamW "
+                            "kernel on the device (no host read in the step)"}
 
     # ---- the same step with the padded caption tokens computed, as HF's BertModel does (secondary figure, same process) ----------
     dense_text = None
@@ -750,39 +810,34 @@ def main():
         finally:
             _tw._GELU8, _tw._RES16, _tw._XHAT_Y = compact0
 
-    # ---- the same step in the reference's own AMP type: fp16 compute + a live GradScaler (clip_runner.py:226-230, core/hooks/
-    # optimizer.py:73-82) - the fp16 flavour of the same kernels (secondary figure, same process; single-rank runs only: the scaler's
-    # skip decision is per rank)
-    fp16_amp = None
-    if world == 1 and os.environ.get("SIMSEG_BENCH_FP16", "1") != "0":
-        os.environ["SIMSEG_AMD_COMPUTE"] = "fp16"
-        opt.half_dtype = torch.float16            # the optimizer kernel's 16-bit weight copies follow the compute type
-        opt._plans.clear()
-        from simseg_amd.optim import GradScaler
-        scaler = GradScaler("cuda")     # torch.amp.GradScaler (its defaults, as the reference constructs it: scale 65536, back-off 0.5, growth every 2000 clean steps) with this package's one-kernel overflow check
+    # ---- the same step in the OTHER 16-bit type (secondary figure, same process): bf16 without a scaler when the headline is the reference's
+    # fp16 AMP, and the other way round
+    other_leg = None
+    OTHER = "bf16" if HEAD == "fp16" else "fp16"
+    if os.environ.get("SIMSEG_BENCH_OTHER_DTYPE_LEG", os.environ.get("SIMSEG_BENCH_FP16", "1")) != "0":
+        set_mode(OTHER)
         try:
-            def step16():
-                opt.zero_grad(set_to_none=True)
-                loss_dict, _, _ = net(next_batch())
-                scaler.scale(loss_dict["nce_loss"]).backward()
-                scaler.step(opt)
-                scaler.update()
             for _ in range(max(3, args.warmup)):
-                step16()
+                step()
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
-            skipped0 = opt.steps_taken()
+            taken1 = opt.steps_taken() if OTHER == "fp16" else 0
             t2 = time.perf_counter()
             for _ in range(args.steps):
-                step16()
+                step()
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
-            el3 = time.perf_counter() - t2
-            fp16_amp = {"pairs_per_s": round(B * args.steps / el3, 2), "ms_per_step": round(1e3 * el3 / args.steps, 3),
-                        "loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt.steps_taken() - skipped0, "steps": args.steps,
-                        "note": "GradScaler live: scaled backward; overflow check = one read-only kernel, unscale + skip decision inside the AdamW kernel on the device (no host read in the step)"}
+            el3 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+            other_leg = {"dtype": OTHER, "pairs_per_s": round(world * B * args.steps / float(el3), 2), "ms_per_step": round(1e3 * float(el3) / args.steps, 3)}
+            if OTHER == "fp16":
+                other_leg.update({"loss_scale": scaler.get_scale(), "optimizer_steps_taken": opt.steps_taken() - taken1, "steps": args.steps})
         finally:
-            os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
-            opt.half_dtype = torch.bfloat16
-            opt._plans.clear()
+            set_mode(HEAD)
+            step()                           # (weight copies of the headline type are back before the instrumented step)
 
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
     # The timed steps run the two towers on two HIP streams (their kernels share the GPU, so a per-kernel duration is not
@@ -805,7 +860,8 @@ def main():
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
     ops.PROFILE = None
-    attn_roofline = attention_roofline(dev, B, args.img, L) if rank == 0 else {}
+    attn_roofline = attention_roofline(dev, B, args.img, L, dtype=HALF[HEAD]) if rank == 0 else {}
+    os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"          # (the evaluation legs below choose their own type)
     del net, model, opt, batches
     torch.cuda.empty_cache()
     seg = None
@@ -897,7 +953,11 @@ def main():
             "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",
             "value_is": "training image-text pairs/s over all ranks; the zero-shot-seg eval rate is reported in seg_eval", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": HEAD, "data": "synthetic",
+            "dtype_is": ("fp16 compute with fp32 accumulation and fp32 master weights under a live GradScaler - the reference's own AMP arithmetic "
+                         "(clip_runner.py:226-230, core/hooks/optimizer.py:73-82)" if HEAD == "fp16" else "bf16 compute, fp32 accumulation, fp32 master weights, no loss scaling"),
+            "amp": amp_info,
+            f"value_{OTHER}": other_leg["pairs_per_s"] if other_leg else None, f"ms_per_step_{OTHER}": other_leg["ms_per_step"] if other_leg else None,
             "config": {"workload": f"ViT-B/16 + BERT-base contrastive pretrain step (fwd + global InfoNCE + bwd + AdamW), "
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
@@ -953,7 +1013,7 @@ def main():
                                                 "vit_layernorm_backward_normalised_value": "from the saved 16-bit output where the gains allow it" if _tw._XHAT_Y else "from the fp32 input",
                                                 "fidelity": "mean 1 - cosine of every parameter gradient to the exact-fp32 backward, ViT-B + BERT-base, B = 256: 4.64e-4 "
                                                             "(all compact forms) vs 4.63e-4 (round-3 forms): tests/test_gpu_fullsize.py"},
-                           "fp16_amp_with_gradscaler": fp16_amp},
+                           "same_step_in_the_other_16_bit_type": other_leg},
             "seg_eval": seg,
             "retrieval_eval": retr,
             "cpu_baseline": cpu,

@@ -164,6 +164,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Full-wave sum through the DPP network (no LDS crossbar, no index registers): quad butterflies, half-row / row mirrors, then the two
+// row broadcasts that gfx9-family DPP offers; the total arrives in lane 63 and is returned as a wave-uniform (scalar) value.
+// All 64 lanes must be active.
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+#define SS_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+    SS_DPP_ADD(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    SS_DPP_ADD(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    SS_DPP_ADD(0x141, 0xf);     // row_half_mirror
+    SS_DPP_ADD(0x140, 0xf);     // row_mirror
+    SS_DPP_ADD(0x142, 0xa);     // row_bcast15 -> rows 1, 3
+    SS_DPP_ADD(0x143, 0xc);     // row_bcast31 -> rows 2, 3
+#undef SS_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

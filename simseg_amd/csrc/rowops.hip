@@ -2,6 +2,7 @@
 // BERT embedding gather/scatter (K9), LoDA top-k pooling + L2norm fwd/bwd (K11, K12), row norms, column sums,
 // casts and transposes.  Every kernel moves 16 bytes per lane per access and reduces rows with wave shuffles.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      bf16_t* __restrict__ y2, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // wave-uniform: scalar row bases
     if (row >= rows) return;
     const int nch = D >> 2;
     const float* xr = x + (long)row * D;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
-    const float mean = wave_sum(s) / D;
+    const float mean = wave_sum_uniform(s) / D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    const float rstd = rsqrtf(wave_sum_uniform(q) / D + eps);
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
@@ -95,6 +96,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Writes dx32 (fp32 residual-gradient stream) and dx16 (bf16 copy fed to the next dgrad/wgrad GEMMs, optionally with
 // the forward dropout mask of the producing dense layer re-applied); dgamma/dbeta and the column sums of dx16 (= the
 // bias gradient of that dense layer) are accumulated with one atomic per column per block.
+//
+// Round 5: the per-column parameters (gamma, and with y16 1/gamma and beta) live in LDS instead of registers (round 4's y16 form held them
+// next to the three column accumulators: 148 VGPRs at D = 768, 3 waves per SIMD, 768 of 1024 blocks resident), the row index is
+// wave-uniform (scalar row bases), and the host sizes the grid from hipOccupancyMaxActiveBlocksPerMultiprocessor: one resident round
+// whatever the register count.  The 16-bit ViT step's form (dy16 + y16 + dres16 -> dx16) runs ln_bwd16_kernel below.
 template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
                                                      const float* __restrict__ dres, const bf16_t* __restrict__ dres16,
@@ -106,34 +112,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      int rows, int D,
                                                      unsigned long long drop_seed, unsigned int drop_thresh, float drop_scale) {
     __shared__ float red[3][1024];   // [dgamma|dbeta|dxsum][wave * 256 + lane * 4 + j]
+    extern __shared__ float par[];   // [gamma | 1/gamma | beta][D]   (the last two only with y16)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    float ag[MAXC][4], ab[MAXC][4], as[MAXC][4], gm[MAXC][4];
+    float ag[MAXC][4], ab[MAXC][4], as[MAXC][4];
     // y16 (round 4): the normalised value xhat = (x - mean) * rstd is taken from the layer's saved 16-bit OUTPUT y = xhat * gamma + beta instead of
     // its fp32 input - half the bytes of the kernel's largest read - for every 4-channel chunk whose gains allow it (|gamma| >= 0.05 and
     // |beta| <= 4 |gamma|: the 16-bit rounding of y then perturbs xhat by <= 1 %); the other chunks read x as before, exactly.
-    float ig[MAXC][4], bt[MAXC][4];
-    bool fromy[MAXC];
+    unsigned fromy = 0;              // bit i: chunk lane + 64 i takes xhat from y16
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; gm[i][j] = 0.f; ig[i][j] = 0.f; bt[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; }
         const int c = lane + 64 * i;
-        fromy[i] = false;
         if (c < nch) {
-            load4<float>(gamma + c * 4, gm[i]);
+            float gm[4];
+            load4<float>(gamma + c * 4, gm);
+            if (wave == 0) store4<float>(par + c * 4, gm);
             if (y16) {
-                load4<float>(beta + c * 4, bt[i]);
+                float bt[4], ig[4];
+                load4<float>(beta + c * 4, bt);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { ok = ok && fabsf(gm[i][j]) >= 0.05f && fabsf(bt[i][j]) <= 4.f * fabsf(gm[i][j]); ig[i][j] = 1.0f / gm[i][j]; }
-                fromy[i] = ok;
+                for (int j = 0; j < 4; ++j) { ok = ok && fabsf(gm[j]) >= 0.05f && fabsf(bt[j]) <= 4.f * fabsf(gm[j]); ig[j] = 1.0f / gm[j]; }
+                if (ok) fromy |= 1u << i;
+                if (wave == 0) { store4<float>(par + D + c * 4, ig); store4<float>(par + 2 * D + c * 4, bt); }
             }
         }
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    __syncthreads();
+    // (row index made wave-uniform for the compiler: row bases are then scalar registers and a lane's address is one 32-bit offset plus an
+    //  immediate per chunk, instead of a 64-bit VGPR pair per pointer and chunk - 119 -> ~90 registers at D = 768)
+    for (int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float g[MAXC][4], xh[MAXC][4], rr[MAXC][4];
+        const long ro = (long)row * D;
+        float g[MAXC][4], xh[MAXC][4];
+        float rr[MAXC][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
@@ -141,54 +155,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 4; ++j) rr[i][j] = 0.f;
             if (c < nch) {
-                const long o = (long)row * D + c * 4;
-                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4];
+                const int o = c * 4;
+                float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4], xv[4], gm[4];
                 if (dy16) {
-                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dy16 + o));
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dy16 + ro + o));
                     a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3];
                 }
-                if (dy32) { load4<float>(dy32 + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
-                if (fromy[i]) {
-                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(y16 + o));
+                if (dy32) { load4<float>(dy32 + ro + o, b); for (int j = 0; j < 4; ++j) a[j] += b[j]; }
+                if ((fromy >> i) & 1u) {
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(y16 + ro + o));
+                    float ig[4], bt[4];
+                    load4<float>(par + D + c * 4, ig);
+                    load4<float>(par + 2 * D + c * 4, bt);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[j] = ((float)t[j] - bt[i][j]) * ig[i][j];       // = xhat
+                    for (int j = 0; j < 4; ++j) xv[j] = ((float)t[j] - bt[j]) * ig[j];       // = xhat
                 } else {
-                    load4_nt(x + o, xv);
+                    load4_nt(x + ro + o, xv);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[j] = (xv[j] - mu) * rs;
                 }
-                if (dres) load4_nt(dres + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
+                if (dres) load4_nt(dres + ro + o, rr[i]);       // requested with the rest of the row: one memory round trip per row
                 if (dres16) {                              // the residual gradient as the previous kernel's 16-bit copy (round 4: half the bytes)
-                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dres16 + o));
+                    const bf16x4 t = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dres16 + ro + o));
                     rr[i][0] += (float)t[0]; rr[i][1] += (float)t[1]; rr[i][2] += (float)t[2]; rr[i][3] += (float)t[3];
                 }
+                load4<float>(par + c * 4, gm);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = xv[j];
                     ag[i][j] += a[j] * xh[i][j];
                     ab[i][j] += a[j];
-                    g[i][j] = a[j] * gm[i][j];
+                    g[i][j] = a[j] * gm[j];
                     s1 += g[i][j];
                     s2 += g[i][j] * xh[i][j];
                 }
             }
         }
-        s1 = wave_sum(s1) / D;
-        s2 = wave_sum(s2) / D;
+        s1 = wave_sum_uniform(s1) / D;
+        s2 = wave_sum_uniform(s2) / D;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
-                const long o = (long)row * D + c * 4;
+                const int o = c * 4;
                 float out[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + rr[i][j];
-                if (dx32) store4_nt(dx32 + o, out);
+                if (dx32) store4_nt(dx32 + ro + o, out);
                 if (drop_thresh) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) out[j] = dropout_keep(drop_seed, (unsigned long long)o + j, drop_thresh) ? out[j] * drop_scale : 0.f;
+                    for (int j = 0; j < 4; ++j) out[j] = dropout_keep(drop_seed, (unsigned long long)(ro + o) + j, drop_thresh) ? out[j] * drop_scale : 0.f;
                 }
-                if (dx16) store4<bf16_t>(dx16 + o, out);
+                if (dx16) store4<bf16_t>(dx16 + ro + o, out);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) as[i][j] += out[j];
             }
@@ -214,6 +232,165 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float sg = 0.f, sb = 0.f, ss = 0.f;
                 for (int w = 0; w < 4; ++w) { sg += red[0][w * 256 + lane * 4 + j]; sb += red[1][w * 256 + lane * 4 + j]; ss += red[2][w * 256 + lane * 4 + j]; }
                 if (partials) {      // [block][3][D] plain stores; ln_bwd_reduce_kernel folds the blocks (1 atomic per column in total)
+                    float* pb = partials + (long)blockIdx.x * 3 * D + c * 4 + j;
+                    pb[0] = sg; pb[D] = sb; pb[2 * D] = ss;
+                } else {
+                    atomicAdd(dgamma + c * 4 + j, sg);
+                    atomicAdd(dbeta + c * 4 + j, sb);
+                    if (dxsum) atomicAdd(dxsum + c * 4 + j, ss);
+                }
+            }
+        }
+    }
+}
+
+// The 16-bit ViT step's LayerNorm backward (round 5): dy16 + y16 + dres16 -> dx16, nothing fp32 in or out (8 bytes per element).
+//   * straight-line row loop: every load of a row is issued before the first use (the generic kernel above waits per 4-channel chunk -
+//     the compiler closes each `if (c < nch)` / `if (fromy)` region with s_waitcnt vmcnt(0), three loads in flight per wave); FULL = the
+//     row is exactly MAXC * 256 channels, no lane predicate at all (D = 768, 512, 256, 1024), otherwise addresses are clamped and values
+//     masked - still no branch around a load;
+//   * the next row's dy / y loads are issued as soon as this row's raw values are converted: in flight during the two wave reductions,
+//     the second pass and the stores; the residual gradient (second pass only) is requested at the top of the row;
+//   * row index wave-uniform (scalar row bases), row sums through the DPP network into scalar registers (wave_sum_uniform: the
+//     ds_bpermute butterfly cost 12 serialized LDS-crossbar round trips per row and 6 index registers);
+//   * per-column parameters in LDS as in the generic kernel, re-read per row (sched_barriers keep the compiler from hoisting all nine
+//     b128 reads - 36 registers - or double-buffering the prefetch in registers).
+// Chunks whose gain fails the y16 test of the generic kernel (`okmask`; decided per launch, uniformly, `needx`) take xhat from the fp32
+// input x, requested at the top of the row - same arithmetic as the generic kernel chunk by chunk.
+template <int MAXC, bool FULL>
+__global__ __launch_bounds__(256) void ln_bwd16_kernel(const bf16_t* __restrict__ dy16, const bf16_t* __restrict__ dres16,
+                                                       const float* __restrict__ x, const bf16_t* __restrict__ y16, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx16, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ dxsum, float* __restrict__ partials,
+                                                       int rows, int D,
+                                                       unsigned long long drop_seed, unsigned int drop_thresh, float drop_scale) {
+    __shared__ float red[3][1024];   // [dgamma|dbeta|dxsum][wave * 256 + lane * 4 + j]
+    extern __shared__ float par[];   // [gamma | 1/gamma | beta][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    float ag[MAXC][4], ab[MAXC][4], as[MAXC][4];
+    unsigned okmask = 0;             // bit i: chunk lane + 64 i takes xhat from y16
+    int off[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; as[i][j] = 0.f; }
+        const int c = lane + 64 * i;
+        off[i] = (FULL || c < nch) ? c * 4 : 0;
+        if (FULL || c < nch) {
+            float gm[4], bt[4], ig[4];
+            load4<float>(gamma + c * 4, gm);
+            load4<float>(beta + c * 4, bt);
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ok = ok && fabsf(gm[j]) >= 0.05f && fabsf(bt[j]) <= 4.f * fabsf(gm[j]); ig[j] = 1.0f / gm[j]; }
+            if (ok) okmask |= 1u << i;
+            if (wave == 0) { store4<float>(par + c * 4, gm); store4<float>(par + D + c * 4, ig); store4<float>(par + 2 * D + c * 4, bt); }
+        } else {
+            okmask |= 1u << i;
+        }
+    }
+    const bool needx = !__all(okmask == (1u << MAXC) - 1u);      // the same answer in every wave of the grid (each wave sees all of gamma / beta)
+    __syncthreads();
+    const int stride = gridDim.x * 4;
+    int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    bf16x4 rdy[MAXC], ry[MAXC];
+#define LN16_ISSUE(R)                                                                                             \
+    do {                                                                                                          \
+        const long ro_ = (long)(R) * D;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MAXC; ++i) {                                                        \
+            rdy[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dy16 + ro_ + off[i]));            \
+            ry[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(y16 + ro_ + off[i]));              \
+        }                                                                                                         \
+    } while (0)
+    if (row < rows) LN16_ISSUE(row);
+    for (; row < rows; row += stride) {
+        const float rs = rstd[row];
+        const long ro = (long)row * D;
+        float g[MAXC][4], xh[MAXC][4];
+        bf16x4 rcur[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+        asm volatile("" ::: "memory");       // the LDS parameter reads below are loop-invariant: keep them in the loop
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) rcur[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(dres16 + ro + off[i]));
+        if (needx) {                         // (xh[] is not live yet: the fp32 rows land in its registers)
+            const float mu = mean[row];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+                if (!((okmask >> i) & 1u)) {
+                    load4_nt(x + ro + off[i], xh[i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xh[i][j] = (xh[i][j] - mu) * rs;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool valid = FULL || c < nch;
+            const bool fromy = !needx || ((okmask >> i) & 1u);
+            float gm[4], ig[4], bt[4];
+            if (i) __builtin_amdgcn_sched_barrier(0);
+            load4<float>(par + off[i], gm);
+            load4<float>(par + D + off[i], ig);
+            load4<float>(par + 2 * D + off[i], bt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = valid ? (float)rdy[i][j] : 0.f;
+                const float fy = ((float)ry[i][j] - bt[j]) * ig[j];
+                xh[i][j] = valid ? (fromy ? fy : xh[i][j]) : 0.f;
+                ag[i][j] += a * xh[i][j];
+                ab[i][j] += a;
+                g[i][j] = a * gm[j];
+                s1 += g[i][j];
+                s2 += g[i][j] * xh[i][j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        { const int nr = row + stride < rows ? row + stride : row; LN16_ISSUE(nr); }      // (the last row re-reads itself: no branch, no copies)
+        __builtin_amdgcn_sched_barrier(0);
+        s1 = wave_sum_uniform(s1) / D;
+        s2 = wave_sum_uniform(s2) / D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool valid = FULL || c < nch;
+            float out[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = rs * (g[i][j] - s1 - xh[i][j] * s2) + (float)rcur[i][j];
+            if (drop_thresh) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = dropout_keep(drop_seed, (unsigned long long)(ro + off[i]) + j, drop_thresh) ? out[j] * drop_scale : 0.f;
+            }
+            if (valid) {
+                store4<bf16_t>(dx16 + ro + off[i], out);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) as[i][j] += out[j];
+            }
+        }
+    }
+#undef LN16_ISSUE
+    // cross-wave reduction of the column partials (as in ln_bwd_kernel)
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        __syncthreads();
+        if (FULL || c < nch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[0][wave * 256 + lane * 4 + j] = ag[i][j];
+                red[1][wave * 256 + lane * 4 + j] = ab[i][j];
+                red[2][wave * 256 + lane * 4 + j] = as[i][j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && (FULL || c < nch)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sg = 0.f, sb = 0.f, ss = 0.f;
+                for (int w = 0; w < 4; ++w) { sg += red[0][w * 256 + lane * 4 + j]; sb += red[1][w * 256 + lane * 4 + j]; ss += red[2][w * 256 + lane * 4 + j]; }
+                if (partials) {
                     float* pb = partials + (long)blockIdx.x * 3 * D + c * 4 + j;
                     pb[0] = sg; pb[D] = sb; pb[2 * D] = ss;
                 } else {
@@ -615,6 +792,27 @@ inline int grid_for(long n, int block, int cap = 4096) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// One resident round of the LayerNorm backward: blocks per CU from the runtime's occupancy calculator for the instantiation's registers
+// and LDS (cached per instantiation and LDS size), times the CU count.  Round 4 launched a fixed 1024 blocks; at 148 VGPRs 768 of them
+// were resident and a quarter-full second round followed.
+constexpr int LN_BWD_MAX_GRID = 2048;
+inline int ln_bwd_grid(const void* fn, int slot, size_t lds, long rows) {
+    static int cached[32];           // blocks per device for instantiation `slot` (0 = not asked yet)
+    static size_t cached_lds[32];
+    int per_dev = (slot >= 0 && slot < 32 && cached_lds[slot] == lds) ? cached[slot] : 0;
+    if (per_dev <= 0) {
+        int per_cu = 0, dev = 0, ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
+        if (const char* e = getenv("SIMSEG_LN_BWD_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }     // (tools/ln_bench.py sweeps)
+        per_dev = per_cu * ncu;
+        if (slot >= 0 && slot < 32) { cached[slot] = per_dev; cached_lds[slot] = lds; }
+    }
+    const int want = grid_for(rows, 4, LN_BWD_MAX_GRID);
+    return want < per_dev ? want : per_dev;
+}
+
 
 // ---- fp32 operand -> three bf16 pieces, laid out for ONE bf16 GEMM that reproduces the fp32 product -----------------------------
 // x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three round-to-nearest pieces of 8 significant
@@ -687,18 +885,34 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     SS_CHECK(D % 4 == 0 && D <= LN_MAXC * 256 && D > 0, "layernorm_bwd: bad D=%lld", (long long)D);
     SS_CHECK(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: dropout p out of range");
     if (rows <= 0) return 0;
-    const int grid = grid_for(rows, 4, 1024);
     const unsigned int thresh = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int nc = (int)((D + 255) / 256);
+    // the 16-bit ViT step's form - dy16 + y16 + dres16 -> dx16 and nothing in fp32 - has its own kernel
+    const bool fast = dy_bf16 && y_bf16 && dres_bf16 && dx_bf16 && !dy_f32 && !dres && !dx_f32;
+    const size_t lds = (size_t)(y_bf16 ? 3 : 1) * D * sizeof(float);
+    const bool full = D % 256 == 0;
+    int grid = 0;
 #define LN_BWD_LAUNCH(C)                                                                                                              \
-    hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, (const bf16_t*)dres_bf16, x, (const bf16_t*)y_bf16, beta, mean, rstd, gamma, \
-                       dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale)
-    if (nc <= 1) LN_BWD_LAUNCH(1);
-    else if (nc == 2) LN_BWD_LAUNCH(2);
-    else if (nc == 3) LN_BWD_LAUNCH(3);
-    else if (nc == 4) LN_BWD_LAUNCH(4);
-    else LN_BWD_LAUNCH(8);
+    do {                                                                                                                              \
+        grid = ln_bwd_grid((const void*)ln_bwd_kernel<C>, C * 3, lds, rows);                                                          \
+        hipLaunchKernelGGL(ln_bwd_kernel<C>, dim3(grid), dim3(256), lds, STREAM, (const bf16_t*)dy_bf16, dy_f32, dres, (const bf16_t*)dres_bf16, x, (const bf16_t*)y_bf16, beta, mean, rstd, gamma, \
+                           dx_f32, (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale); \
+    } while (0)
+#define LN_BWD16_LAUNCH(C, F)                                                                                                         \
+    do {                                                                                                                              \
+        grid = ln_bwd_grid((const void*)ln_bwd16_kernel<C, F>, C * 3 + (F ? 1 : 2), lds, rows);                                       \
+        hipLaunchKernelGGL((ln_bwd16_kernel<C, F>), dim3(grid), dim3(256), lds, STREAM, (const bf16_t*)dy_bf16, (const bf16_t*)dres_bf16, x, (const bf16_t*)y_bf16, beta, mean, rstd, gamma, \
+                           (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale); \
+    } while (0)
+#define LN_BWD_PICK(C) do { if (!fast) LN_BWD_LAUNCH(C); else if (full) LN_BWD16_LAUNCH(C, true); else LN_BWD16_LAUNCH(C, false); } while (0)
+    if (nc <= 1) LN_BWD_PICK(1);
+    else if (nc == 2) LN_BWD_PICK(2);
+    else if (nc == 3) LN_BWD_PICK(3);
+    else if (nc == 4) LN_BWD_PICK(4);
+    else LN_BWD_PICK(8);
+#undef LN_BWD_PICK
+#undef LN_BWD16_LAUNCH
 #undef LN_BWD_LAUNCH
     if (partials)
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * D + 255) / 256), 32), dim3(256), 0, STREAM, partials, grid, (int)D,
@@ -707,8 +921,8 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     return 0;
 }
 
-/* floats the caller must provide as `partials` for a launch over `rows` rows of width D */
-extern "C" int64_t simseg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, 1024) * 3 * D * (int64_t)sizeof(float); }
+/* floats the caller must provide as `partials` for a launch over `rows` rows of width D (the grid never exceeds LN_BWD_MAX_GRID blocks) */
+extern "C" int64_t simseg_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)grid_for(rows, 4, LN_BWD_MAX_GRID) * 3 * D * (int64_t)sizeof(float); }
 
 extern "C" int simseg_colsum_accum(const void* in, int in_dtype, float* out, int64_t rows, int64_t N, int64_t ld, void* stream) {
     SS_HALF_FWD(simseg_colsum_accum, in, in_dtype, out, rows, N, ld, stream);

@@ -379,6 +379,48 @@ def test_layernorm_bwd_16bit_residual_and_xhat_from_the_saved_output(ops, D):
         assert float((res["x"][0][:, lo:lo + 4] - res["y"][0][:, lo:lo + 4]).abs().max()) <= 2e-2 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("D", [256, 384, 768, 1024, 1280])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_layernorm_bwd_16bit_step_form_many_rows(ops, D, mixed):
+    """Round 5's kernel of the 16-bit step form (ln_bwd16_kernel: dy16 + y16 + dres16 -> dx16): more rows than one resident round of waves (the
+    software-pipelined row loop runs 2-3 times per wave and ends on its self-re-read), rows exactly MAXC * 256 wide and ragged ones, every
+    gain eligible for the y16 read and a mix that needs x, with the fused column sums and the dropout mask.  Against the fp64 derivative and
+    against the generic kernel (x path) on the same inputs."""
+    rows = 9001
+    x = _rand(rows, D, seed=1, scale=2.0) + 0.3
+    g, b = torch.exp(_rand(D, seed=2) * 0.5), _rand(D, seed=3) * 0.2
+    if mixed:
+        g[3] = 0.01; g[D - 2] = -0.03; b[D // 2] = 30.0
+    y, y16, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, want_bf16_copy=True, save_stats=True)
+    dy16, dres16 = _rand(rows, D, seed=5, dtype=torch.bfloat16), _rand(rows, D, seed=6, dtype=torch.bfloat16)
+    xr = x.double().requires_grad_(True); gr = g.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy16.double())
+    want = xr.grad + dres16.double()
+    out = {}
+    for tag, kw in (("x", {}), ("y", dict(y16=y16, beta=b))):
+        dgam = torch.zeros(D, device="cuda"); dbet = torch.zeros(D, device="cuda"); dsum = torch.zeros(D, device="cuda")
+        _, dx16 = ops.layernorm_bwd(x, mean, rstd, g, dgam, dbet, dy16=dy16, dres16=dres16, want_f32=False, dxsum=dsum, **kw)
+        out[tag] = (dx16.double(), dgam.double(), dbet.double(), dsum.double())
+    rel = lambda a, w: float((a - w).norm() / w.norm())       # noqa: E731
+    ex, ey = rel(out["x"][0], want), rel(out["y"][0], want)
+    assert ex < 3e-3 and ey < 1.3 * ex + 2e-4, (ex, ey)
+    ok = torch.ones(D, dtype=torch.bool, device="cuda")
+    if mixed:                                                  # the two tiny gains' dgamma is only as good as xhat from x is: compared on the x path below
+        ok[3] = ok[D - 2] = False
+    assert rel(out["y"][1][ok], gr.grad[ok]) < 5e-3
+    assert rel(out["y"][1], out["x"][1]) < 5e-3                # ... and the fall-back chunks match the generic kernel's
+    assert rel(out["y"][2], br.grad) < 1e-5
+    assert rel(out["y"][3], want.sum(0)) < 2e-2 and rel(out["y"][3], out["y"][0].sum(0)) < 1e-2   # column sums of what was written (taken before its 16-bit rounding)
+    # dropout mask of the producing dense layer re-applied to the written copy, column sums of the masked values
+    dgam = torch.zeros(D, device="cuda"); dbet = torch.zeros(D, device="cuda"); dsum = torch.zeros(D, device="cuda")
+    _, dxm = ops.layernorm_bwd(x, mean, rstd, g, dgam, dbet, dy16=dy16, dres16=dres16, want_f32=False, dxsum=dsum, drop_seed=77, drop_p=0.1, y16=y16, beta=b)
+    keep = torch.ones(rows, D, device="cuda")
+    ops.dropout_apply_(keep, 77, 0.1)
+    assert rel(dxm.double(), out["y"][0] * keep.double()) < 5e-3
+    assert torch.equal(dxm == 0, (keep == 0) | (dxm == 0))
+    assert rel(dsum.double(), dxm.double().sum(0)) < 1e-2
+
+
 def test_colsum_transpose_cast(ops):
     x = _rand(1001, 776, seed=1)
     out = torch.ones(776, device="cuda")

@@ -364,6 +364,34 @@ def test_ping_pong_gemm_kernels_spill_nothing_outside_the_saved_derivative_epilo
     assert all(seen[k] > 0 for k in seen), seen
 
 
+def test_layernorm_backward_kernels_fit_four_waves_per_simd():
+    """Code-object metadata of the built rowops.o: the LayerNorm backward instantiations that run the ViT-S / ViT-B step (D = 384 -> MAXC 2,
+    D = 768 -> MAXC 3; generic form and the 16-bit step form ln_bwd16_kernel) stay within 128 VGPRs - four 256-thread blocks per CU - and spill
+    nothing.  Round 4's y16 form went from 124 to 148 registers unnoticed (768 of its 1024 blocks resident, 133 -> 214 us per call)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    seen = set()
+    for obj in ("rowops.o", "rowops_h16.o"):
+        path = os.path.join(REPO, "simseg_amd", "build", obj)
+        if not os.path.exists(path):
+            pytest.skip("simseg_amd/build/*.o not present (the library was built elsewhere)")
+        for name, vgpr, spill, scratch, lds in kr.kernel_resources(path):
+            m = re.search(r"ln_bwd(16)?_kernelILi(\d)E(?:Lb(\d)E)?", name)
+            if not m:
+                continue
+            fast, maxc, full = m.group(1) is not None, int(m.group(2)), m.group(3)
+            if maxc > 3 or (fast and maxc == 3 and full == "0"):       # (D = 768 is always the FULL instantiation; wider rows are not on the step's path)
+                continue
+            seen.add((obj, fast, maxc))
+            assert vgpr <= 128 and spill == 0 and scratch == 0, (obj, name, vgpr, spill, scratch)
+    assert {(o, f, c) for o in ("rowops.o", "rowops_h16.o") for f in (False, True) for c in (2, 3)} <= seen, seen
+
+
 def test_gradsync_zero_copy_targets():
     """GradSync.begin() arms the zero-copy path: a backward function that accumulates its weight gradient into towers._grad_target(param)
     (a fresh, zero-filled view of the exchange buffer) hands autograd a tensor it ADOPTS as .grad - the bucket hand-over then copies
