@@ -22,6 +22,15 @@
 // ds_read_b128 / ds_read_b64_tr_b16 fragment fetches are bank-conflict free.
 #include "common.h"
 
+// Epilogue ablation switches of tools/dbg_fc1_epilogue.py (skip the GELU' store / the GELU itself / the output store through
+// simseg_debug_gemm_stagger(1001..1003)) exist only in builds made with -DSS_GEMM_ABLATE: in the shipped library a left-over debug value
+// cannot silently produce wrong activations, and simseg_debug_gemm_stagger refuses values >= 1000.
+#ifdef SS_GEMM_ABLATE
+#define SS_ABL(v) (p.stagger == (v))
+#else
+#define SS_ABL(v) false
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
@@ -1013,17 +1022,17 @@ __device__ __forceinline__ void pp_epilogue_bf16(const GemmParams& p, const f32x
             for (int e = 0; e < 16; ++e) {           // the left / right element as one pair: packed fp32 arithmetic (common.h)
                 f32x2 d;
                 f32x2 y = __builtin_elementwise_fma((f32x2){acc[i][0][e], acc[i][1][e]}, (f32x2){p.alpha, p.alpha}, (f32x2){bL, bR});
-                if (p.stagger != 1002) y = gelu_poly_grad2(y, d); else d = y;
+                if (!SS_ABL(1002)) y = gelu_poly_grad2(y, d); else d = y;
                 l[e] = y.x; r[e] = y.y;
                 dl.h[e] = (bf16_t)d.x; dr.h[e] = (bf16_t)d.y;
             }
-            if (p.stagger != 1001)
+            if (!SS_ABL(1001))
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 *reinterpret_cast<u32x4*>(Bb + (i * 2) * 1024 + q * 8) = dl.v[q];
                 *reinterpret_cast<u32x4*>(Bb + (i * 2 + 1) * 1024 + q * 8) = dr.v[q];
             }
-            if (p.stagger != 1003) emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
+            if (!SS_ABL(1003)) emit(l, r, Cb, m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32);
         }
     } else if (EK == 1 && p.act == 4) {
         // times the saved derivative (the dgrad through fc2) + column sums (fc1's bias gradient).  The saved tensor is row-major like the
@@ -2005,7 +2014,13 @@ extern "C" int simseg_gemm_last_variant(void) {
     SS_HALF_FWD(simseg_gemm_last_variant); return g_gemm_last_variant; }
 
 // debugging: the ping-pong kernel writes 5 x u64 per block (start / K loop start / K loop end / end wall-clock stamps at 100 MHz, HW_ID)
-extern "C" int simseg_debug_gemm_stagger(int ticks) { g_gemm_stagger = ticks; return 0; }
+extern "C" int simseg_debug_gemm_stagger(int ticks) {
+#ifndef SS_GEMM_ABLATE
+    SS_CHECK(ticks < 1000, "debug_gemm_stagger: %d selects an epilogue ablation, which this build does not contain (-DSS_GEMM_ABLATE)", ticks);
+#endif
+    g_gemm_stagger = ticks;
+    return 0;
+}
 extern "C" int simseg_debug_gemm_wgrad_blocks(int blocks) {
 #ifndef SS_HALF
     simseg_debug_gemm_wgrad_blocks_h16(blocks);

@@ -70,7 +70,9 @@ static __global__ __launch_bounds__(RM_THREADS) void ragged_maps_kernel(const in
     }
     if (tid == 0) cnt[B] = total;
     __syncthreads();
-    for (int b = tid; b <= B; b += RM_THREADS) row_start[b] = cnt[b];
+    // (positions never reach past the caller's [cap, D] buffers: when the host-side token count the buffers were sized from is smaller than
+    //  what the mask holds - reported through info[2] one step later - the surplus tokens are dropped here instead of indexed out of bounds)
+    for (int b = tid; b <= B; b += RM_THREADS) row_start[b] = min(cnt[b], cap);
     // (3) rank of every real token inside its sequence -> idx / inv
     for (int b = wave; b < B; b += NW) {
         int at = cnt[b];
@@ -80,7 +82,7 @@ static __global__ __launch_bounds__(RM_THREADS) void ragged_maps_kernel(const in
             const unsigned long long bal = __ballot(m);
             const int pos = at + __popcll(bal & ((1ull << lane) - 1ull));
             if (l < L) {
-                inv[(long)b * L + l] = m ? pos : -1;
+                inv[(long)b * L + l] = (m && pos < cap) ? pos : -1;
                 if (m && pos < cap) idx[pos] = b * L + l;
             }
             at += __popcll(bal);

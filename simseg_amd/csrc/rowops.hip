@@ -891,7 +891,6 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
     // the 16-bit ViT step's form - dy16 + y16 + dres16 -> dx16 and nothing in fp32 - has its own kernel
     const bool fast = dy_bf16 && y_bf16 && dres_bf16 && dx_bf16 && !dy_f32 && !dres && !dx_f32;
     const size_t lds = (size_t)(y_bf16 ? 3 : 1) * D * sizeof(float);
-    const bool full = D % 256 == 0;
     int grid = 0;
 #define LN_BWD_LAUNCH(C)                                                                                                              \
     do {                                                                                                                              \
@@ -905,7 +904,7 @@ extern "C" int simseg_layernorm_bwd(const void* dy_bf16, const float* dy_f32, co
         hipLaunchKernelGGL((ln_bwd16_kernel<C, F>), dim3(grid), dim3(256), lds, STREAM, (const bf16_t*)dy_bf16, (const bf16_t*)dres_bf16, x, (const bf16_t*)y_bf16, beta, mean, rstd, gamma, \
                            (bf16_t*)dx_bf16, dgamma, dbeta, dxsum, partials, (int)rows, (int)D, (unsigned long long)drop_seed, thresh, scale); \
     } while (0)
-#define LN_BWD_PICK(C) do { if (!fast) LN_BWD_LAUNCH(C); else if (full) LN_BWD16_LAUNCH(C, true); else LN_BWD16_LAUNCH(C, false); } while (0)
+#define LN_BWD_PICK(C) do { if (!fast) LN_BWD_LAUNCH(C); else if (D == (C) * 256) LN_BWD16_LAUNCH(C, true); else LN_BWD16_LAUNCH(C, false); } while (0)
     if (nc <= 1) LN_BWD_PICK(1);
     else if (nc == 2) LN_BWD_PICK(2);
     else if (nc == 3) LN_BWD_PICK(3);

@@ -199,7 +199,10 @@ class ClipLossFn(Function):
             (dsi_t, dst_t, txtg_t, imgg_t, txt_t, img_t), dt = ops.transpose_multi([ds[0], ds[1], txt_g, img_g, txt32, img32], [1, 1, 0, 0, 0, 0],
                                                                                     scalar=g, alpha=0.5, x0=x0)
         dimg = dtxt = None
-        through_gather = world == 1 or ctx.gb          # (one rank: the "gathered" embeddings are the local ones, gradients flow through both roles)
+        # gradients flow through the gathered role with gather_backward, and with NO process group (NCE._gather then returns the local
+        # tensor itself).  A real group of one rank with gather_backward=False detaches like all_gather_rows / the reference's
+        # all_gather_group (utils/dist.py:65-74) - same gradients as the unfused NCE.forward path.
+        through_gather = ctx.gb or ctx.group is None
         if need_img:
             dimg = ops.gemm(ds[0], txtg_t)                                   # dS_i . txt_g          [Bl, P]
             if through_gather:

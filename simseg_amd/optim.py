@@ -198,8 +198,9 @@ class AdamW(torch.optim.Optimizer):
               for p in params:                 # same stream as the next forward: the copies are current when it runs
                   register_w16(p, self.state[p]["p16"])
                   drop_split_copy(p)           # the exact-mode split-bf16 copy of the OLD value (raw-pointer update: _version did not move)
-        if amp:
-            self._amp_calls += 1             # (several buckets: every launch of this call read the same slot and wrote the other)
+        if amp and ready:
+            self._amp_calls += 1             # (several buckets: every launch of this call read the same slot and wrote the other; a call
+                                             #  with no gradient at all launched nothing - the other slot was not written, so do not flip)
 
     # ---- checkpoints in torch.optim.AdamW's layout ---------------------------------------------------------------------
     def state_dict(self):

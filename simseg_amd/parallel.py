@@ -62,6 +62,7 @@ class GradSync:
         self._comm = None
         self._handles = []
         self._armed = False
+        self._handed = [False] * len(self.params)
         self._split_done = False
         # Which gradients need an event of their own.  A bucket is handed over on the stream that produced its LAST gradient; members
         # produced on that same stream are ordered by the stream itself, and with the towers on two streams that is all but a handful per
@@ -87,6 +88,13 @@ class GradSync:
             when this step was not armed with begin()."""
             if not self._armed:
                 return None
+            # Handed out ONCE per step and only while the parameter has no gradient tensor yet.  Otherwise autograd's AccumulateGrad would
+            # run `p.grad += view` with both aliasing the same memory (a stale flat view kept by zero_grad(set_to_none=False), or a second
+            # Function application of the same parameter in one backward): 2x gradients, silently.  Returning None makes the backward
+            # function allocate its own gradient tensor, which autograd then accumulates - and the bucket hand-over copies - as usual.
+            if self._handed[i] or self.params[i].grad is not None:
+                return None
+            self._handed[i] = True
             v = self.views[i]
             return v.view(v.shape)
         return target
@@ -94,9 +102,12 @@ class GradSync:
     @torch.no_grad()
     def begin(self):
         """Before the forward pass of a step: zero the flat buffer (on the current stream - the tower streams fork from it later) and let the
-        backward functions write the large weight gradients straight into it."""
+        backward functions write the large weight gradients straight into it.  Precondition for the zero-copy hand-over of a parameter:
+        its .grad is None when its backward runs (zero_grad(set_to_none=True)) and it feeds one Function application per backward; a
+        parameter that does not meet it simply takes the copying path (_make_target)."""
         self.flat.zero_()
         self._armed = True
+        self._handed = [False] * len(self.params)
         self._copied = 0
 
     def close(self):
@@ -166,12 +177,14 @@ class GradSync:
         and the parameters' .grad become those views.  Runs on the stream of the bucket's last gradient, behind the events of the
         members that another stream produced."""
         src, dst = [], []
+        self._src_stream = {}
         for i in self.buckets[b]["members"]:
             p, v = self.params[i], self.views[i]
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad); dst.append(v)
+                self._src_stream[id(p.grad)] = self._prod[i]      # (None = not seen by a hook this step: treated as foreign)
         self._copied += len(dst)
         if self.flat.is_cuda:
             cur = torch.cuda.current_stream()
@@ -191,6 +204,14 @@ class GradSync:
                 self._nev += 1
         if dst:
             torch._foreach_copy_(dst, src)
+            if self.flat.is_cuda:
+                # a source gradient produced on ANOTHER stream lives in that stream's allocator pool; `p.grad = view` below drops its last
+                # reference, and without this the block could be handed back to its producer (still running its backward) and overwritten
+                # before the copy enqueued on `cur` has executed
+                cur = torch.cuda.current_stream()
+                for g_ in src:
+                    if self._src_stream.get(id(g_)) != cur:
+                        g_.record_stream(cur)
         for i in self.buckets[b]["members"]:
             self.params[i].grad = self.views[i]
         if self.flat.is_cuda:

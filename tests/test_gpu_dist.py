@@ -325,3 +325,67 @@ def test_gradsync_overlap_equals_ddp_and_sharded_retrieval_equals_single(world):
     multi, single = out[0]["retr_multi"], out[0]["retr_single"]
     assert multi == single, (multi, single)      # same dot products, same integer ranks: bit-equal
     assert 0.0 < multi["coco_I2T-R@1"] < 100.0 and len(multi) == 7
+
+
+def _worker_ws1(rank, world, port, backend, q):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=0, world_size=1)
+    try:
+        from simseg_amd.heads import ClipLossFn, NCEFn, all_gather_rows, GatherLayer
+        g = torch.Generator().manual_seed(0)
+        res = {}
+        for gb in (False, True):
+            img = torch.nn.functional.normalize(torch.randn(48, 64, generator=g), dim=1).cuda().requires_grad_(True)
+            txt = torch.nn.functional.normalize(torch.randn(48, 64, generator=g), dim=1).cuda().requires_grad_(True)
+            temp = torch.tensor(0.07, device="cuda", requires_grad=True)
+            loss, _, _ = ClipLossFn.apply(img, txt, temp, dist.group.WORLD, 0, 0.0, gb)
+            loss.backward()
+            fused = (img.grad.clone(), txt.grad.clone(), temp.grad.clone())
+            img.grad = txt.grad = temp.grad = None
+            gather = (lambda t: GatherLayer.apply(t, dist.group.WORLD, 0)) if gb else (lambda t: all_gather_rows(t, dist.group.WORLD))
+            l1, _ = NCEFn.apply(img, gather(txt), temp, None, None, 0, 0.0)
+            l2, _ = NCEFn.apply(txt, gather(img), temp, None, None, 0, 0.0)
+            (0.5 * (l1 + l2)).backward()
+            res[gb] = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(fused, (img.grad, txt.grad, temp.grad))] + [float(loss - 0.5 * (l1 + l2))]
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_loss_head_equals_unfused_in_a_one_rank_group():
+    """A REAL process group of one rank: with gather_backward=False the gathered role carries no gradient (all_gather_rows detaches, as the
+    reference's all_gather_group does, utils/dist.py:65-74) - the fused head ClipLossFn once let it through in exactly this configuration
+    (up to 2x embedding gradients against NCE.forward's path); with gather_backward=True both roles carry it.  Fused == unfused either way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_ws1, args=(0, 1, _free_port(), "gloo", q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    for gb, errs in res.items():
+        assert max(errs[:3]) < 1e-5 and abs(errs[3]) < 1e-6, (gb, errs)
+
+
+def test_bench_self_launches_two_ranks_on_rccl():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run, one rank per GPU, and
+    the process group is RCCL (`nccl`) on two different devices.  Needs two visible devices (the 1-GPU test box skips it; the driver's
+    8-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: RCCL refuses two ranks on it (the gloo two-rank tests above cover the exchange arithmetic)")
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--pairs-per-gpu", "64",
+                          "--no-seg", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    pg = line["config"]["process_group"]
+    assert line["n_gpus"] == 2 and pg["backend"] == "nccl" and pg["world_size"] == 2 and "warning" not in pg, pg
+    assert len({r["device"] for r in pg["ranks"]}) == 2
+    assert line["config"]["global_batch"] == 128 and line["value"] > 0
