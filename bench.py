@@ -274,7 +274,7 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
     # read by the argmax pass as the reference's temp_pred[...] stack would be: counted for visited ones only.)
     post_bytes = img * img * (4 * visited + windows)
     out = {"post_ms_per_step": round(post_ms, 3), "post_visited_candidates_per_window": round(visited / windows, 2),
-           "windows_per_s": round(wps, 1), "images_per_s_3_windows_each": round(wps / 3, 1), "dtype": dtype, "window": img,
+           "windows_per_s": round(wps, 1), "dtype": dtype, "window": img,
            "classes": classes, "windows_per_batch": windows, "batches_in_flight": 2, "dense_crf": bool(crf),
            "tflops_per_gpu": round(wps / world * fl / 1e12, 1)}
     if crf:
@@ -306,6 +306,74 @@ def seg_eval_bench(dev, world, dtype, windows=63, steps=3, img=512, classes=171,
         out["frac_of_peak_counts"] = "6 bf16 piece products per algorithmic fp32 product, against the dense bf16 MFMA peak (the pipe the kernels use)"
         out["fp32_equivalent_frac_of_fp32_mfma_peak"] = round(wps / world * fl / PEAK_F32, 4)
     return out
+
+
+def seg_slide_bench(dev, world, dtype, images=21, steps=3, H=512, W=1024, win=512, stride=256, classes=171, tag="vit_base_patch16_224_in21k",
+                    dim=768, crf=True, window_batch=None):
+    """BASELINE configs[3] as SURVEY.md 8d cfg 4 defines it: COCO-Stuff-shaped 512 x 1024 source images, 3 windows of 512^2 at stride 256
+    each, ViT-B towers per window, per-window patch x class-text similarity maps OVERLAP-AVERAGED on the source image's 32 x 64 patch grid
+    (simseg_stitch_windows), then ONE per-image body (candidates, min-max, DenseCRF on the 512 x 1024 image, closing, argmax, IoU areas) per
+    source image; images/s counts SOURCE images.  Source images are independent: every rank runs its own batches (weak shard) and the
+    [3, C] histograms meet in one all-reduce at the end (segpost.evaluate_sharded is the product form of this loop)."""
+    from simseg.models import PIPELINE
+    from simseg_amd import segpost
+    os.environ["SIMSEG_AMD_COMPUTE"] = dtype
+    cfg, build = build_model(tag, dim, win)
+    torch.manual_seed(7)
+    model = build(cfg.model.name, cfg, PIPELINE).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(classes, 512, generator=g), dim=-1).to(dev)
+    # network inputs that ARE images (the DenseCRF reads them back de-normalised): smooth colour fields + noise, normalised as the transforms do
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    base = torch.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) * 127 // max(H, W))], 0).float()
+    nb = min(images, 4)
+    rgb = (base[None] + 20 * torch.randn(nb, 3, H, W, generator=g)).clamp(0, 255)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = ((rgb / 255.0 - mean) / std).repeat((images + nb - 1) // nb, 1, 1, 1)[:images].contiguous().to(dev)
+    labels = torch.randint(0, classes, (images, H, W), generator=g, dtype=torch.int64).to(torch.uint8)
+    labels[torch.rand(images, H, W, generator=g) < 0.05] = 255
+    labels = labels.to(dev)
+    mean, std = mean.to(dev), std.to(dev)
+    hist = torch.zeros(3, classes, device=dev, dtype=torch.int64)
+    cdt = torch.bfloat16 if dtype == "bf16" else None
+    wy, wx = segpost.window_grid(H, W, win, stride)
+
+    def encode():
+        with torch.no_grad():
+            return segpost.encode_batch_sliding(model, x, text, 10, win=win, stride=stride, crf=crf, mean=mean, std=std, sim_dtype=cdt, window_batch=window_batch)
+
+    def finish(st):
+        with torch.no_grad():
+            return segpost.finish_batch(st, labels, hist=hist)
+
+    def run(n_batches):
+        pipe = segpost.EvalPipeline(dev, encode, finish, pipelined=crf and os.environ.get("SIMSEG_SEG_PIPELINE", "1") != "0")
+        for _ in range(n_batches):
+            pipe.submit()
+        return pipe.flush()
+
+    run(2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    last = run(2 * steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    visited = int((last["cand_idx"] >= 0).sum())
+    ips = world * images * 2 * steps / float(el)
+    del model
+    torch.cuda.empty_cache()
+    return {"images_per_s": round(ips, 1), "windows_per_s": round(ips * wy * wx, 1), "source_image": [H, W], "window": win, "stride": stride,
+            "windows_per_image": wy * wx, "stitched_patch_grid": [H // 16, W // 16], "images_per_batch": images, "classes": classes, "dtype": dtype,
+            "dense_crf": bool(crf), "batches_in_flight": 2, "visited_candidates_per_image": round(visited / images, 2),
+            "pixels_labelled": int(hist[2].sum()), "stitch": "overlap-average of the per-window [32,32,C] maps on the [32,64] grid (simseg_stitch_windows), image scores = mean of window scores"}
 
 
 def seg_latency_bench(dev, dtype, img, classes, tag, dim, reps=50):
@@ -873,6 +941,11 @@ def main():
                # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
                "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
                "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
+        # BASELINE configs[3] proper: 512 x 1024 source images through 3 overlapping windows each, stitched maps, images/s = SOURCE images
+        seg["slide_512x1024"] = {"fp32_crf": seg_slide_bench(dev, world, "fp32", images=21, steps=1, crf=True),
+                                 "bf16_crf": seg_slide_bench(dev, world, "bf16", images=256, steps=1, crf=True, window_batch=256),
+                                 "bf16": seg_slide_bench(dev, world, "bf16", images=256, steps=1, crf=False, window_batch=256),
+                                 "images_per_s_is": "source images per second over all ranks (SURVEY.md 8d cfg 4)"}
         if rank == 0:         # single-image latency (the reference tool's batch size), eager launches vs one hipGraph replay
             seg["latency_batch1"] = [seg_latency_bench(dev, "fp32", 288, 21, "vit_small_patch16_224_in21k", 384),
                                      seg_latency_bench(dev, "fp32", 512, 171, "vit_base_patch16_224_in21k", 768),

@@ -291,6 +291,16 @@ int simseg_seg_select(const float* scores, int* cand_idx, float* cand_score, flo
  * with its pairwise terms off), nearest-upsampled x16 (:137) -> mask [B,ncand,16n,16n] bytes.  Invalid slots are not written. */
 int simseg_seg_masks(const float* sim, const int* cand_idx, float* prob, void* mask, int64_t B, int64_t n, int64_t C, int64_t ncand,
                      void* stream);
+/* The same on a rectangular patch grid: sim [B, nh*nw, C] (row-major patch rows), mask [B,ncand,16nh,16nw] - the stitched map of a
+ * sliding-window evaluation (BASELINE configs[3]); simseg_seg_masks is the nh = nw case. */
+int simseg_seg_masks_rect(const float* sim, const int* cand_idx, float* prob, void* mask, int64_t B, int64_t nh, int64_t nw, int64_t C,
+                          int64_t ncand, void* stream);
+/* Sliding-window stitch (BASELINE configs[3] / SURVEY.md 8d cfg 4: 512x512 windows at stride 256 over a larger image, "overlap-average
+ * sim maps"; the reference tool itself resizes to one window, tools/seg_evaluation.py:84-85,109).  win [B, wy, wx, n*n, C] fp32 = the
+ * per-window similarity maps (simseg_patch_text_sim), window (i, j) at patch offset (i*step, j*step); out [B, nh*nw, C] with
+ * nh = n + (wy-1)*step, nw = n + (wx-1)*step: per cell the mean over the covering windows, summed in (i, j) order.  step = 0: the plain
+ * mean over all windows (with n = 1: image-level class scores from per-window scores). */
+int simseg_stitch_windows(const float* win, float* out, int64_t B, int64_t wy, int64_t wx, int64_t n, int64_t step, int64_t C, void* stream);
 /* cv2.dilate / cv2.erode with a 7x7 ones kernel, ONE iteration (the third positional argument in :156-157 is `dst`, not
  * `iterations`), default border (never wins) on byte images [M,H,W]; erode = 0 dilate, 1 erode.  out must not alias in. */
 int simseg_morph7(const void* in, void* out, int64_t M, int64_t H, int64_t W, int erode, void* stream);

@@ -36,8 +36,10 @@ def select_candidates(scores, top_cls_num, ncand=5):
 
 
 def normalised_map(sim_col, n, patch=16):
-    """:135-149: column of the similarity map -> n x n -> nearest x16 -> min-max normalise.  Returns (prob [16n,16n], binary)."""
-    a = sim_col.reshape(n, n).astype(np.float32)
+    """:135-149: column of the similarity map -> n x n -> nearest x16 -> min-max normalise.  Returns (prob [16n,16n], binary).
+    n may be (nh, nw): the stitched patch grid of a sliding-window evaluation."""
+    nh, nw = (n, n) if isinstance(n, int) else n
+    a = sim_col.reshape(nh, nw).astype(np.float32)
     up = np.repeat(np.repeat(a, patch, axis=0), patch, axis=1)
     mn, mx = up.min(), up.max()
     with np.errstate(invalid="ignore", divide="ignore"):
@@ -103,7 +105,8 @@ def segment_image(sim, scores, label, n, top_cls_num, ncand=5, closing=True, fas
     H, W = label.shape
     idx, sc, thr = select_candidates(scores, top_cls_num, ncand)
     temp_pred = np.zeros((C, H, W))                                              # :126 (float64)
-    masks = np.zeros((ncand, 16 * n, 16 * n), np.uint8)
+    nh, nw = (n, n) if isinstance(n, int) else n
+    masks = np.zeros((ncand, 16 * nh, 16 * nw), np.uint8)
     mf = fast_morph or morph7
     for k, index in enumerate(idx):
         if index < 0:
@@ -116,3 +119,34 @@ def segment_image(sim, scores, label, n, top_cls_num, ncand=5, closing=True, fas
     a_i, a_p, a_l = intersect_and_union(pred, label, C)
     return {"pred": pred, "cand_idx": idx, "cand_score": sc, "threshold": thr, "masks": masks,
             "hist": torch.stack([a_i, a_p, a_l]).long()}
+
+
+# ---- sliding-window form (BASELINE configs[3] / SURVEY.md 8d cfg 4; the reference tool has only the single resize, :84-85,109) --------
+def stitch_windows(win_maps, wy, wx, n, step):
+    """win_maps [wy*wx, n*n, C] float32 (window (i, j) at patch offset (i*step, j*step), row-major over the window grid) ->
+    [nh*nw, C]: per cell the mean over the covering windows, accumulated in float32 in (i, j) order - written as the explicit loop."""
+    C = win_maps.shape[-1]
+    nh, nw = n + (wy - 1) * step, n + (wx - 1) * step
+    acc = np.zeros((nh, nw, C), np.float32)
+    cnt = np.zeros((nh, nw), np.int32)
+    for i in range(wy):
+        for j in range(wx):
+            m = win_maps[i * wx + j].reshape(n, n, C).astype(np.float32)
+            acc[i * step:i * step + n, j * step:j * step + n] += m
+            cnt[i * step:i * step + n, j * step:j * step + n] += 1
+    return (acc / cnt[..., None].astype(np.float32)).reshape(nh * nw, C)
+
+
+def sliding_window_image(win_maps, win_scores, label, wy, wx, n, step, top_cls_num, ncand=5, closing=True, fast_morph=None):
+    """One SOURCE image evaluated through wy*wx windows: win_maps [wy*wx, n*n, C] (each window's normalised patch x class map),
+    win_scores [wy*wx, C] (each window's pooled-embedding class scores).  Maps are overlap-averaged on the source patch grid, scores are
+    averaged over the windows (float32, window order), and the reference's per-image body runs once on the stitched map."""
+    sim = stitch_windows(win_maps, wy, wx, n, step)
+    sc = np.zeros(win_scores.shape[1], np.float32)
+    for w in range(wy * wx):
+        sc += win_scores[w].astype(np.float32)
+    sc = sc / np.float32(wy * wx)
+    nh, nw = n + (wy - 1) * step, n + (wx - 1) * step
+    out = segment_image(sim, torch.from_numpy(sc), label, (nh, nw), top_cls_num, ncand, closing, fast_morph)
+    out["sim"], out["scores"] = sim, sc
+    return out

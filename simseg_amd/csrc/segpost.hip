@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void seg_select_kernel(const float* __restrict
 constexpr int MASK_MAXN = 4096;
 __global__ __launch_bounds__(256) void seg_mask_kernel(const float* __restrict__ sim, const int* __restrict__ cand_idx, int N, int n,
                                                        int C, int ncand, float* __restrict__ prob, unsigned char* __restrict__ mask) {
+    // (n = patch columns, N / n = patch rows: square for one resized image, nh x nw for a stitched sliding-window map)
     __shared__ float v[MASK_MAXN];
     __shared__ float rmin[4], rmax[4];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -100,13 +101,46 @@ __global__ __launch_bounds__(256) void seg_mask_kernel(const float* __restrict__
     }
     __syncthreads();
     // x16 nearest: every 16-byte store is one pixel row of one patch cell
-    const int Hm = n * 16;
-    uint4* out = reinterpret_cast<uint4*>(mask + ((long)b * ncand + c) * Hm * Hm);
+    const int Hm = (N / n) * 16, Wm = n * 16;
+    uint4* out = reinterpret_cast<uint4*>(mask + ((long)b * ncand + c) * Hm * Wm);
     const long segs = (long)Hm * n;
     for (long s = tid; s < segs; s += 256) {
         const int y = (int)(s / n), px = (int)(s % n);
         const unsigned w = v[(y >> 4) * n + px] != 0.f ? 0xffffffffu : 0u;
         out[s] = make_uint4(w, w, w, w);
+    }
+}
+
+// K18b (round 5, BASELINE configs[3] "slide-window 512x512"): overlap-average of per-window maps on the source image's patch grid.
+// win [B, wy, wx, n, n, C]: window (i, j) covers source patch rows i*step .. i*step+n-1 and columns j*step .. j*step+n-1 (512-pixel
+// windows at stride 256 on 16-pixel patches: n = 32, step = 16); out [B, nh, nw, C] with nh = n + (wy-1)*step: the mean over the windows
+// that cover each cell, summed in window order (i, then j) - the order the oracle's loop uses, so fp32 results agree bit for bit.
+// step = 0 averages all windows cell by cell (n = 1: the mean of per-window class scores).  HBM-bound, read-once / write-once: one
+// thread per output element, consecutive threads on consecutive classes (the contiguous axis of both tensors).
+__global__ __launch_bounds__(256) void stitch_windows_kernel(const float* __restrict__ win, float* __restrict__ out, int B, int wy, int wx,
+                                                             int n, int step, int C, int nh, int nw) {
+    const long total = (long)B * nh * nw * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int x = (int)(r % nw); r /= nw;
+        const int y = (int)(r % nh);
+        const int b = (int)(r / nh);
+        // windows covering row y: i*step <= y <= i*step + n - 1
+        int i0 = 0, i1 = wy - 1, j0 = 0, j1 = wx - 1;
+        if (step > 0) {
+            i0 = max(0, (y - n + step) / step); i1 = min(wy - 1, y / step);
+            j0 = max(0, (x - n + step) / step); j1 = min(wx - 1, x / step);
+        }
+        float acc = 0.f;
+        int cnt = 0;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+                const int ly = y - i * step, lx = x - j * step;
+                acc += win[((((long)b * wy + i) * wx + j) * n * n + (long)ly * n + lx) * C + c];
+                ++cnt;
+            }
+        out[e] = acc / (float)cnt;
     }
 }
 
@@ -313,14 +347,34 @@ extern "C" int simseg_seg_select(const float* scores, int* cand_idx, float* cand
     return 0;
 }
 
+extern "C" int simseg_seg_masks_rect(const float* sim, const int* cand_idx, float* prob, void* mask, int64_t B, int64_t nh, int64_t nw,
+                                     int64_t C, int64_t ncand, void* stream) {
+    SS_CHECK(sim && cand_idx && mask, "seg_masks: null pointer");
+    SS_CHECK(B > 0 && nh > 0 && nw > 0 && nh * nw <= MASK_MAXN && C > 0 && ncand >= 1 && ncand <= 8, "seg_masks: bad shape (nh*nw <= %d)", MASK_MAXN);
+    SS_CHECK(((uintptr_t)mask % 16) == 0, "seg_masks: mask must be 16-byte aligned");
+    hipLaunchKernelGGL(seg_mask_kernel, dim3((unsigned)ncand, (unsigned)B), dim3(256), 0, (hipStream_t)stream, sim, cand_idx, (int)(nh * nw),
+                       (int)nw, (int)C, (int)ncand, prob, static_cast<unsigned char*>(mask));
+    SS_LAUNCH_CHECK("seg_masks");
+    return 0;
+}
+
 extern "C" int simseg_seg_masks(const float* sim, const int* cand_idx, float* prob, void* mask, int64_t B, int64_t n, int64_t C,
                                 int64_t ncand, void* stream) {
-    SS_CHECK(sim && cand_idx && mask, "seg_masks: null pointer");
-    SS_CHECK(B > 0 && n > 0 && n * n <= MASK_MAXN && C > 0 && ncand >= 1 && ncand <= 8, "seg_masks: bad shape (n*n <= %d)", MASK_MAXN);
-    SS_CHECK(((uintptr_t)mask % 16) == 0, "seg_masks: mask must be 16-byte aligned");
-    hipLaunchKernelGGL(seg_mask_kernel, dim3((unsigned)ncand, (unsigned)B), dim3(256), 0, (hipStream_t)stream, sim, cand_idx, (int)(n * n),
-                       (int)n, (int)C, (int)ncand, prob, static_cast<unsigned char*>(mask));
-    SS_LAUNCH_CHECK("seg_masks");
+    return simseg_seg_masks_rect(sim, cand_idx, prob, mask, B, n, n, C, ncand, stream);
+}
+
+extern "C" int simseg_stitch_windows(const float* win, float* out, int64_t B, int64_t wy, int64_t wx, int64_t n, int64_t step, int64_t C,
+                                     void* stream) {
+    SS_CHECK(win && out && win != out, "stitch_windows: null or aliased pointers");
+    SS_CHECK(B > 0 && wy > 0 && wx > 0 && n > 0 && step >= 0 && step <= n && C > 0, "stitch_windows: bad shape (0 <= step <= n)");
+    const long nh = n + (wy - 1) * step, nw = n + (wx - 1) * step;
+    const long total = (long)B * nh * nw * C;
+    SS_CHECK(total < (1ll << 40), "stitch_windows: problem too large");
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(stitch_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, win, out, (int)B, (int)wy, (int)wx, (int)n,
+                       (int)step, (int)C, (int)nh, (int)nw);
+    SS_LAUNCH_CHECK("stitch_windows");
     return 0;
 }
 

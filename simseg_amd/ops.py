@@ -501,16 +501,32 @@ def seg_select(scores, top_cls_num, ncand=5):
 
 
 def seg_masks(sim, cand_idx, n, want_prob=False):
-    """sim [B,n*n,C] fp32, cand_idx [B,ncand] -> mask [B,ncand,16n,16n] uint8 (0/255; skipped slots all zero), prob or None."""
+    """sim [B,nh*nw,C] fp32, cand_idx [B,ncand] -> mask [B,ncand,16nh,16nw] uint8 (0/255; skipped slots all zero), prob or None.
+    n: the patch grid - an int (n x n, one resized image) or (nh, nw) (a stitched sliding-window map)."""
     require_gpu(sim, cand_idx)
     B, N, C = sim.shape
-    if N != n * n:
-        raise ValueError(f"seg_masks: sim has {N} patches, expected {n}x{n}")
+    nh, nw = (n, n) if isinstance(n, int) else (int(n[0]), int(n[1]))
+    if N != nh * nw:
+        raise ValueError(f"seg_masks: sim has {N} patches, expected {nh}x{nw}")
     ncand = cand_idx.shape[1]
-    mask = torch.zeros(B, ncand, 16 * n, 16 * n, device=sim.device, dtype=torch.uint8)
+    mask = torch.zeros(B, ncand, 16 * nh, 16 * nw, device=sim.device, dtype=torch.uint8)
     prob = torch.zeros(B, ncand, N, device=sim.device, dtype=torch.float32) if want_prob else None
-    call("simseg_seg_masks", ptr(_c(sim)), ptr(_c(cand_idx)), ptr(prob) if want_prob else None, ptr(mask), B, n, C, ncand, stream())
+    call("simseg_seg_masks_rect", ptr(_c(sim)), ptr(_c(cand_idx)), ptr(prob) if want_prob else None, ptr(mask), B, nh, nw, C, ncand, stream())
     return mask, prob
+
+
+def stitch_windows(win, wy, wx, n, step):
+    """win [B*wy*wx, n*n, C] fp32 (per-window maps, windows of an image consecutive, row-major over the window grid) -> [B, nh*nw, C]:
+    the overlap-average on the source image's patch grid, nh = n + (wy-1)*step, nw = n + (wx-1)*step (simseg_stitch_windows)."""
+    require_gpu(win)
+    M, N, C = win.shape
+    if win.dtype != torch.float32 or N != n * n or M % (wy * wx):
+        raise ValueError(f"stitch_windows: fp32 [B*{wy}*{wx}, {n}*{n}, C] maps expected, got {tuple(win.shape)} {win.dtype}")
+    B = M // (wy * wx)
+    nh, nw = n + (wy - 1) * step, n + (wx - 1) * step
+    out = torch.empty(B, nh * nw, C, device=win.device, dtype=torch.float32)
+    call("simseg_stitch_windows", ptr(_c(win)), ptr(out), B, wy, wx, n, step, C, stream())
+    return out
 
 
 def morph7(img, erode):

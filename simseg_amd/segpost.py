@@ -79,7 +79,8 @@ def segment_finish(st, labels, num_classes=None, ignore_index=255, refine=None, 
     num_classes = num_classes or st["num_classes"]
     if refine is not None or images_u8 is not None:
         B, K, N = prob.shape
-        lo = prob.view(B, K, num_patch, num_patch)
+        nh, nw = (num_patch, num_patch) if isinstance(num_patch, int) else num_patch
+        lo = prob.view(B, K, nh, nw)
         if refine is not None:
             up = lo.repeat_interleave(16, 2).repeat_interleave(16, 3)
             masks = refine(up, cand_idx, cand_score).to(torch.uint8).contiguous()
@@ -114,6 +115,109 @@ def encode_batch(model, image, text, top_cls_num, crf=True, mean=None, std=None,
     st = segment_begin(sim, ops.gemm(pooled.float(), text), n, top_cls_num, need_prob=refine is not None or raw is not None)
     st["images_u8"] = raw
     return st
+
+
+# ---- sliding-window evaluation (BASELINE configs[3]: "ViT-B zero-shot seg eval, COCO-Stuff-shaped 171 classes, slide-window 512x512") ----
+# The reference tool resizes every image to ONE network input (tools/seg_evaluation.py:84-85,109); SURVEY.md 8d cfg 4 defines the
+# sliding-window form this package adds: windows of `win` pixels at stride `stride` over the (larger) source image, each window through the
+# towers as an image of its own, the per-window patch x class similarity maps overlap-AVERAGED on the source image's patch grid, and then the
+# reference's per-image body (candidate classes, min-max, DenseCRF, 7x7 closing, resize, score-weighted argmax, IoU areas) ONCE per source
+# image on the stitched map.  Image-level class scores (:112-123 works on the pooled embedding of the one resized image) are the mean of
+# the windows' scores.  oracle/segpost_ref.py sliding_window_image() is the per-image loop this is tested against.
+
+def window_grid(H, W, win=512, stride=256):
+    """-> (wy, wx): windows per column / row.  The image must be tiled exactly: (H - win) and (W - win) multiples of the stride (the
+    caller pads or resizes otherwise), win and stride multiples of the 16-pixel patch."""
+    if win % 16 or stride % 16 or stride <= 0 or stride > win:
+        raise ValueError(f"window_grid: win {win} and stride {stride} must be multiples of the 16-pixel patch with 0 < stride <= win")
+    if H < win or W < win or (H - win) % stride or (W - win) % stride:
+        raise ValueError(f"window_grid: a {H}x{W} image is not tiled exactly by {win}-pixel windows at stride {stride}")
+    return (H - win) // stride + 1, (W - win) // stride + 1
+
+
+def extract_windows(image, win=512, stride=256):
+    """image [B,3,H,W] -> [B*wy*wx, 3, win, win]: an image's windows consecutive, row-major over its window grid (a strided copy)."""
+    B, C, H, W = image.shape
+    wy, wx = window_grid(H, W, win, stride)
+    v = image.unfold(2, win, stride).unfold(3, win, stride)            # [B, C, wy, wx, win, win] view
+    return v.permute(0, 2, 3, 1, 4, 5).reshape(B * wy * wx, C, win, win)
+
+
+def encode_batch_sliding(model, image, text, top_cls_num, win=512, stride=256, crf=True, mean=None, std=None, sim_dtype=None, window_batch=None):
+    """encode_batch() for source images larger than the network input: image [B,3,H,W] -> B*wy*wx windows through the towers (at most
+    `window_batch` windows per call), similarity maps stitched on the [H/16, W/16] patch grid (ops.stitch_windows), image-level scores =
+    the mean of the windows' pooled scores -> candidate selection and min-max maps on the stitched grid.  Device work only."""
+    from .heads import patch_text_similarity
+    B, _, H, W = image.shape
+    wy, wx = window_grid(H, W, win, stride)
+    wins = extract_windows(image, win, stride)
+    n = win // 16
+    sims, scores = [], []
+    wb = window_batch or wins.shape[0]
+    for s in range(0, wins.shape[0], wb):
+        feats = model.forward_image_feature(wins[s:s + wb])          # [b, n*n, D]
+        pooled = model.forward_image_project(feats)                   # [b, 512]
+        sims.append(patch_text_similarity(model.image_projection(feats), text, compute_dtype=sim_dtype))
+        scores.append(ops.gemm(pooled.float(), text))
+    sim_w = sims[0] if len(sims) == 1 else torch.cat(sims)
+    sc_w = scores[0] if len(scores) == 1 else torch.cat(scores)
+    sim = ops.stitch_windows(sim_w.float(), wy, wx, n, stride // 16)                       # [B, nh*nw, C]
+    sc = ops.stitch_windows(sc_w.float().view(B * wy * wx, 1, -1), wy, wx, 1, 0).view(B, -1)      # mean over an image's windows
+    raw = None
+    if crf:
+        raw = (((image * std) + mean) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    st = segment_begin(sim, sc, (H // 16, W // 16), top_cls_num, need_prob=raw is not None)
+    st["images_u8"] = raw
+    st["windows"] = (wy, wx)
+    return st
+
+
+def shard_batches(batches, rank, world):
+    """Round-robin shard of an iterable of batches: rank r takes batches r, r + world, ... (independent units, no data-path collective)."""
+    for i, b in enumerate(batches):
+        if i % world == rank:
+            yield b
+
+
+def evaluate_sharded(model, batches, text, top_cls_num, num_classes=None, group=None, slide=None, crf=True, mean=None, std=None, sim_dtype=None,
+                     device=None, pipelined=None, window_batch=None):
+    """The zero-shot segmentation evaluation over `batches` = an iterable of (image [b,3,H,W], label [b,Hl,Wl] uint8) - the SAME iterable on
+    every rank - data-parallel over the ranks of `group` (default: the world, or a single process when torch.distributed is not
+    initialised): batches are dealt round-robin (shard_batches; the reference's loader gives every rank every image,
+    simseg/datasets/seg/seg_dataset.py:67-81), each rank accumulates its [3, C] area histograms on its device and ONE all-reduce(SUM) of that
+    tensor ends the evaluation (simseg/utils/metrics.py:85-97 sums the same three vectors over the images).  slide = (win, stride): the
+    sliding-window form (encode_batch_sliding); None: one network input per image (encode_batch).
+    -> dict(iou [C] float64, miou, hist [3,C] int64 (global), images (global count), images_local)."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    C = num_classes or text.shape[0]
+    dev = torch.device(device) if device is not None else text.device
+    hist = torch.zeros(3, C, device=dev, dtype=torch.int64)
+
+    def encode(image, label):
+        if slide is not None:
+            return encode_batch_sliding(model, image, text, top_cls_num, win=slide[0], stride=slide[1], crf=crf, mean=mean, std=std,
+                                        sim_dtype=sim_dtype, window_batch=window_batch)
+        return encode_batch(model, image, text, top_cls_num, crf=crf, mean=mean, std=std, sim_dtype=sim_dtype)
+
+    def finish(st, image, label):
+        return finish_batch(st, label, hist=hist)
+
+    count = 0
+    pipe = EvalPipeline(dev, encode, finish, pipelined=crf if pipelined is None else pipelined)
+    with torch.no_grad():
+        for image, label in shard_batches(batches, rank, world):
+            pipe.submit(image.to(dev, non_blocking=True), label.to(dev, non_blocking=True))
+            count += image.shape[0]
+        pipe.flush()
+    n_img = torch.tensor([count], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)          # the evaluation's only collective: 3*C int64 areas
+        dist.all_reduce(n_img, op=dist.ReduceOp.SUM, group=group)
+    iou, miou = iou_from_hist(hist)
+    return {"iou": iou, "miou": miou, "hist": hist, "images": int(n_img), "images_local": count, "rank": rank, "world": world}
 
 
 def finish_batch(st, label, hist=None, refine=None, want_pred=False):

@@ -389,3 +389,68 @@ def test_bench_self_launches_two_ranks_on_rccl():
     assert line["n_gpus"] == 2 and pg["backend"] == "nccl" and pg["world_size"] == 2 and "warning" not in pg, pg
     assert len({r["device"] for r in pg["ranks"]}) == 2
     assert line["config"]["global_batch"] == 128 and line["value"] > 0
+
+
+def _worker_seg_sharded(rank, world, port, backend, q):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if torch.cuda.device_count() >= world else 0), SIMSEG_AMD_COMPUTE="fp32")
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from simseg_amd import segpost
+        from test_gpu_miou_gate import MEAN, STD, _build, _voc_like
+        win, stride, H, W, C, top = 96, 48, 96, 192, 21, 10
+        g = torch.Generator().manual_seed(3)
+        text = torch.nn.functional.normalize(torch.randn(C, 512, generator=g), dim=-1).to(dev)
+        model = _build("vit_test_patch16", 128, "bert-test", 128, win, seed=5).eval().to(dev)
+        mean = torch.tensor(MEAN, device=dev).view(1, 3, 1, 1)
+        std = torch.tensor(STD, device=dev).view(1, 3, 1, 1)
+        batches = []
+        for i in range(5):                                   # 5 batches over 2 ranks: 3 + 2 (ragged shard), batch sizes 2 and 1
+            b = 2 if i % 2 == 0 else 1
+            _, x = _voc_like(b, W, seed=60 + i)
+            lab = torch.randint(0, C, (b, H, W), generator=g, dtype=torch.int64).to(torch.uint8)
+            batches.append((x[:, :, :H].contiguous(), lab))
+        res = segpost.evaluate_sharded(model, batches, text, top, slide=(win, stride), crf=True, mean=mean, std=std, device=dev)
+        plain = segpost.evaluate_sharded(model, [(x[:, :, :win, :win].contiguous(), l[:, :win, :win].contiguous()) for x, l in batches], text, top,
+                                         slide=None, crf=False, device=dev)
+        out = {"hist": res["hist"].cpu(), "images": res["images"], "local": res["images_local"], "miou": float(res["miou"]),
+               "plain_hist": plain["hist"].cpu(), "plain_images": plain["images"]}
+        if rank == 0:      # the single-process answer: every batch, no group (computed inside the group's process but without using it)
+            hist = torch.zeros(3, C, device=dev, dtype=torch.int64)
+            hist_p = torch.zeros(3, C, device=dev, dtype=torch.int64)
+            with torch.no_grad():
+                for x, lab in batches:
+                    st = segpost.encode_batch_sliding(model, x.to(dev), text, top, win=win, stride=stride, crf=True, mean=mean, std=std)
+                    segpost.finish_batch(st, lab.to(dev), hist=hist)
+                    segpost.eval_batch(model, x[:, :, :win, :win].contiguous().to(dev), lab[:, :win, :win].contiguous().to(dev), text, top, hist=hist_p, crf=False)
+            out["want"], out["want_plain"] = hist.cpu(), hist_p.cpu()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_seg_evaluation_two_ranks_equals_single_process():
+    """segpost.evaluate_sharded on two ranks (round-robin batches, ONE all-reduce of the [3, C] area histograms - DESIGN section 5's "seg eval
+    shards by image") == the single-process evaluation of every batch: sliding-window form with the DenseCRF and the plain one-input form.
+    nccl where two devices are visible, gloo with both ranks on cuda:0 otherwise."""
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_seg_sharded, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert got[0]["images"] == got[1]["images"] == 8 and {got[0]["local"], got[1]["local"]} == {6, 2}
+    assert torch.equal(got[0]["hist"], got[1]["hist"]) and torch.equal(got[0]["hist"], got[0]["want"])
+    assert int(got[0]["hist"][2].sum()) <= 8 * 96 * 192 and int(got[0]["hist"][1].sum()) > 0
+    assert torch.equal(got[0]["plain_hist"], got[0]["want_plain"]) and got[0]["plain_images"] == 8

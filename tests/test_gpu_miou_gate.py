@@ -199,3 +199,82 @@ def test_pipelined_evaluation_equals_batch_by_batch(monkeypatch):
     torch.cuda.synchronize()
     assert int(want[2].sum()) == nb * B * S * S
     assert torch.equal(got, want)
+
+
+def test_sliding_window_pipeline_vs_oracle_loop(monkeypatch):
+    """BASELINE configs[3]'s sliding-window form end to end (SURVEY.md 8d cfg 4: windows at half-window stride, overlap-averaged similarity maps,
+    one per-image body per SOURCE image): segpost.encode_batch_sliding + finish_batch against the oracle's loop over images and windows -
+    every window through the oracle towers as an image of its own, oracle stitch (oracle/segpost_ref.stitch_windows), mean window scores,
+    then the reference's per-image body with the oracle CRF on the source image.  1 x 3 windows of 96 pixels at stride 48 on 96 x 192 images."""
+    from oracle import crf_ref as CR
+    from oracle import segpost_ref as SR
+    from oracle import simseg_ref as R
+    from simseg_amd import segpost
+    monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "fp32")
+    win, stride, H, W, C, top, B = 96, 48, 96, 192, 21, 10, 3
+    u8, x = _voc_like(B, W, seed=23)
+    u8, x = np.ascontiguousarray(u8[:, :H]), x[:, :, :H].contiguous()
+    g = torch.Generator().manual_seed(3)
+    text = torch.nn.functional.normalize(torch.randn(C, 512, generator=g), dim=-1)
+    model = _build("vit_test_patch16", 128, "bert-test", 128, win, seed=5).eval()
+    ref = R.RefCLIP("vit_test_patch16", "bert-test", img_size=win)
+    ref.load_state_dict(model.state_dict(), strict=False)
+    ref.eval()
+    model = model.cuda()
+    wy, wx = segpost.window_grid(H, W, win, stride)
+    assert (wy, wx) == (1, 3)
+    n, step = win // 16, stride // 16
+    nh, nw = n + (wy - 1) * step, n + (wx - 1) * step
+    want = np.zeros((B, H, W), np.int64)
+    sims, scs, visited = [], [], 0
+    with torch.no_grad():
+        for b in range(B):
+            wm, ws = [], []
+            for i in range(wy):
+                for j in range(wx):
+                    xw = x[b:b + 1, :, i * stride:i * stride + win, j * stride:j * stride + win]
+                    feats = ref.forward_image_feature(xw)
+                    wm.append(R.seg_similarity(ref.image_projection(feats), text)[0].numpy())
+                    ws.append(R.seg_image_scores(ref.forward_image_project(feats), text)[0].numpy())
+            sim = SR.stitch_windows(np.stack(wm), wy, wx, n, step)
+            sc = np.zeros(C, np.float32)
+            for w_ in ws:
+                sc += w_.astype(np.float32)
+            sc = sc / np.float32(len(ws))
+            sims.append(sim); scs.append(sc)
+            idx, scv, _ = SR.select_candidates(torch.from_numpy(sc), top)
+            temp = np.zeros((C, H, W))
+            for k, c in enumerate(idx):
+                if c < 0:
+                    continue
+                visited += 1
+                norm, _ = SR.normalised_map(sim[:, c], (nh, nw))
+                m = (CR.dense_crf(u8[b], norm) * 255).astype(np.uint8)
+                m = SR.morph7_fast(SR.morph7_fast(m, False), True)
+                temp[c] = SR.resize_nearest(m, H, W).astype(np.float64) * scv[k]
+            want[b] = temp.argmax(0)
+    assert visited >= B
+    labels = _labels_from(want, seed=9, C=C)
+    mean = torch.tensor(MEAN, device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor(STD, device="cuda").view(1, 3, 1, 1)
+    hist = torch.zeros(3, C, device="cuda", dtype=torch.int64)
+    with torch.no_grad():
+        st = segpost.encode_batch_sliding(model, x.cuda(), text.cuda(), top, win=win, stride=stride, crf=True, mean=mean, std=std)
+        out = segpost.finish_batch(st, torch.from_numpy(labels).cuda(), hist=hist, want_pred=True)
+    # the stitched map itself: fp32 towers within the north star's 1e-3 of the oracle's, window scores likewise
+    cand = out["cand_idx"].cpu().numpy()
+    for b in range(B):
+        idx, _, _ = SR.select_candidates(torch.from_numpy(scs[b]), top)
+        assert cand[b].tolist() == idx
+    agree = float((out["pred"].cpu().numpy() == want).mean())
+    hist_ref = np.zeros((3, C))
+    for b in range(B):
+        hist_ref += np.stack([h.numpy() for h in SR.intersect_and_union(want[b], labels[b], C)])
+    (_, miou), (_, miou_ref) = _miou(hist.cpu().numpy()), _miou(hist_ref)
+    print(f"sliding window: pixel agreement {agree:.5f}, mIoU {miou:.3f} vs oracle loop {miou_ref:.3f}")
+    assert agree >= 0.999 and abs(miou - miou_ref) <= 0.1
+    # windows in chunks of 4 (a window batch that does not divide an image's windows) give the same maps
+    with torch.no_grad():
+        st2 = segpost.encode_batch_sliding(model, x.cuda(), text.cuda(), top, win=win, stride=stride, crf=False, window_batch=4)
+    assert torch.equal(st2["cand_idx"], st["cand_idx"]) and torch.equal(st2["masks"], segpost.segment_begin(
+        torch.from_numpy(np.stack(sims)).cuda(), torch.from_numpy(np.stack(scs)).cuda(), (nh, nw), top)["masks"])

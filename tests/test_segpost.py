@@ -208,6 +208,10 @@ def test_device_eval_tool_synthetic():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "6 samples evaluated" in out.stdout and "final mean iou" in (out.stdout + out.stderr)
+    # the sliding-window form (BASELINE configs[3]): 96 x 192 synthetic images through 1 x 3 windows of 96 at stride 48
+    out = subprocess.run(cmd + ["--slide", "96,48"], env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "6 samples evaluated" in out.stdout and "final mean iou" in (out.stdout + out.stderr)
 
 
 # ------------------------------------------------------------------------------------------------------------------ DenseCRF
@@ -399,3 +403,80 @@ def test_dense_crf_reuses_the_spatial_lattice_across_calls(monkeypatch):
         assert torch.equal(m0, m1) and float((q0 - q1).abs().max()) < 1e-5
     again = ops.dense_crf(*cases[3], want_q=True)          # same size as the previous call: reused
     assert calls[-1] == 1 and torch.equal(again[0], want[3][0]) and float((again[1] - want[3][1]).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ sliding window (configs[3])
+def test_oracle_stitch_is_a_partition_of_unity():
+    """Oracle self-checks: windows cut from one global map stitch back to it exactly; a single window is the identity; the count of
+    covering windows is 1 / 2 / 4 where it should be."""
+    rng = np.random.default_rng(0)
+    n, step, wy, wx, C = 4, 2, 2, 3, 5
+    nh, nw = n + (wy - 1) * step, n + (wx - 1) * step
+    glob = rng.standard_normal((nh, nw, C)).astype(np.float32)
+    wins = np.stack([glob[i * step:i * step + n, j * step:j * step + n].reshape(n * n, C) for i in range(wy) for j in range(wx)])
+    np.testing.assert_allclose(SR.stitch_windows(wins, wy, wx, n, step), glob.reshape(-1, C), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(SR.stitch_windows(wins[:1], 1, 1, n, step), wins[0])
+    ones = np.ones((wy * wx, n * n, 1), np.float32)
+    np.testing.assert_array_equal(SR.stitch_windows(ones * 3, wy, wx, n, step), np.full((nh * nw, 1), 3, np.float32))
+
+
+def test_window_grid_and_shards():
+    from simseg_amd import segpost
+    assert segpost.window_grid(512, 1024) == (1, 3) and segpost.window_grid(512, 512) == (1, 1) and segpost.window_grid(1024, 1024) == (3, 3)
+    assert segpost.window_grid(64, 96, win=32, stride=16) == (3, 5)
+    for bad in ((512, 1000), (500, 1024), (256, 512)):
+        with pytest.raises(ValueError):
+            segpost.window_grid(*bad)
+    img = torch.arange(2 * 3 * 64 * 96, dtype=torch.float32).view(2, 3, 64, 96)
+    w = segpost.extract_windows(img, 32, 16)
+    assert w.shape == (2 * 3 * 5, 3, 32, 32)
+    assert torch.equal(w[1 * 15 + 2 * 5 + 3], img[1, :, 32:64, 48:80])
+    assert [list(segpost.shard_batches(range(7), r, 3)) for r in range(3)] == [[0, 3, 6], [1, 4], [2, 5]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wy,wx,n,step,C", [(1, 3, 32, 16, 171), (2, 3, 6, 2, 21), (3, 3, 8, 8, 7), (1, 1, 5, 3, 4), (2, 2, 4, 1, 3)])
+def test_stitch_windows_vs_oracle(wy, wx, n, step, C):
+    """simseg_stitch_windows == the oracle loop, bit for bit (same fp32 sums in the same order), incl. BASELINE configs[3]'s geometry
+    (3 windows of 32x32 patches at a 16-patch stride, 171 classes), no overlap (step = n), a single window, and a 4-fold overlap."""
+    from simseg_amd import ops
+    B = 2
+    rng = np.random.default_rng(5)
+    wins = rng.standard_normal((B, wy * wx, n * n, C)).astype(np.float32)
+    out = ops.stitch_windows(torch.from_numpy(wins).view(B * wy * wx, n * n, C).cuda(), wy, wx, n, step).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(out[b], SR.stitch_windows(wins[b], wy, wx, n, step))
+    sc = rng.standard_normal((B * wy * wx, 1, C)).astype(np.float32)
+    m = ops.stitch_windows(torch.from_numpy(sc).cuda(), wy, wx, 1, 0).cpu().numpy().reshape(B, C)
+    for b in range(B):
+        ref = np.zeros(C, np.float32)
+        for w in range(wy * wx):
+            ref += sc[b * wy * wx + w, 0]
+        np.testing.assert_array_equal(m[b], ref / np.float32(wy * wx))
+
+
+@pytest.mark.gpu
+def test_rectangular_grid_segment_vs_oracle():
+    """select + masks + closing + predict on a NON-square patch grid (the stitched map of a 1 x 3 window row) == the oracle's per-image
+    loop; masks, predictions and histograms bit-equal."""
+    from simseg_amd import segpost
+    B, nh, nw, C, H, W = 2, 4, 8, 21, 64, 128
+    g = torch.Generator().manual_seed(3)
+    sim = torch.randn(B, nh * nw, C, generator=g) * 0.1
+    yy, xx = torch.meshgrid(torch.arange(nh), torch.arange(nw), indexing="ij")
+    for b in range(B):
+        for k, c in enumerate((3, 7, 12)):
+            sim[b, :, c] += torch.exp(-((yy - (1 + k)) ** 2 + (xx - (2 + 2 * k + b)) ** 2) / 6.0).reshape(-1) * 0.5
+    scores = torch.randn(B, C, generator=g) * 0.05
+    for k, c in enumerate((3, 7, 12)):
+        scores[:, c] += 0.4 - 0.05 * k
+    labels = torch.randint(0, C, (B, H, W), generator=g, dtype=torch.int64).to(torch.uint8)
+    out = segpost.segment(sim.cuda(), scores.cuda(), labels.cuda(), (nh, nw), 10)
+    hist = torch.zeros(3, C, dtype=torch.int64)
+    for b in range(B):
+        ref = SR.segment_image(sim[b].numpy(), scores[b], labels[b].numpy(), (nh, nw), 10, fast_morph=SR.morph7_fast)
+        assert out["cand_idx"][b].tolist() == ref["cand_idx"]
+        np.testing.assert_array_equal(out["masks"][b].cpu().numpy(), ref["masks"])
+        np.testing.assert_array_equal(out["pred"][b].cpu().numpy(), ref["pred"])
+        hist += ref["hist"]
+    assert torch.equal(out["hist"].cpu(), hist)

@@ -34,6 +34,9 @@ def parse_args():
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N synthetic images with random weights")
     ap.add_argument("--no-crf", action="store_true", help="skip the DenseCRF (binary map = its unary decision)")
     ap.add_argument("--host-crf", action="store_true", help="DenseCRF with pydensecrf on the host instead of the device kernels")
+    ap.add_argument("--slide", default="", help="WIN,STRIDE: sliding-window evaluation (BASELINE configs[3]): images are fed at their loader size, cut into "
+                                                "WIN-pixel windows at STRIDE, per-window similarity maps overlap-averaged (segpost.encode_batch_sliding); "
+                                                "transforms.input_size must be WIN")
     return ap.parse_known_args()
 
 
@@ -106,8 +109,9 @@ def main():
             g = torch.Generator().manual_seed(1)
             for s in range(0, args.synthetic, args.batch):
                 b = min(args.batch, args.synthetic - s)
-                lab = torch.randint(0, 21, (b, size, size), generator=g, dtype=torch.int64).to(torch.uint8)
-                yield torch.randn(b, 3, size, size, generator=g), lab
+                hw = (size, 2 * size) if args.slide else (size, size)        # sliding window: 1 x 3 windows at half-window stride
+                lab = torch.randint(0, 21, (b, *hw), generator=g, dtype=torch.int64).to(torch.uint8)
+                yield torch.randn(b, 3, *hw, generator=g), lab
             return
         from simseg.datasets.seg.seg_dataset import build_torch_valid_loader
         loader = build_torch_valid_loader(cfg, name, mode="valid")
@@ -150,15 +154,24 @@ def main():
         def finish(st, image, label):
             return segpost.finish_batch(st, label, hist=hist, refine=st["refine"])
 
-        pipe = segpost.EvalPipeline(ENV.device, encode, finish, pipelined=not args.no_crf)
-        with torch.no_grad():
-            for image, label in batches(name):
-                image, label = image.to(ENV.device), label.to(ENV.device)
-                pipe.submit(image, label)
-                count += image.shape[0]
-            pipe.flush()
-        torch.cuda.synchronize()
-        iou, miou = segpost.iou_from_hist(hist)
+        if args.host_crf and not args.no_crf:
+            pipe = segpost.EvalPipeline(ENV.device, encode, finish, pipelined=True)
+            with torch.no_grad():
+                for image, label in batches(name):
+                    image, label = image.to(ENV.device), label.to(ENV.device)
+                    pipe.submit(image, label)
+                    count += image.shape[0]
+                pipe.flush()
+            torch.cuda.synchronize()
+            iou, miou = segpost.iou_from_hist(hist)
+        else:
+            # the product loop: batches dealt round-robin to the ranks of the process group (one rank when launched plainly; N under
+            # `python -m torch.distributed.run --nproc-per-node N tools/seg_eval_device.py ...`), ONE all-reduce of the [3, C] area histograms
+            slide = tuple(int(v) for v in args.slide.split(",")) if args.slide else None
+            res = segpost.evaluate_sharded(model, batches(name), text, top_cls_num, slide=slide, crf=not args.no_crf, mean=mean, std=std,
+                                           device=ENV.device)
+            torch.cuda.synchronize()
+            iou, miou, count = res["iou"], res["miou"], res["images"]
         dt = time.perf_counter() - t0
         print(f"---------------- {count} samples evaluated ({name}, {count / dt:.1f} images/s). ----------------")
         logger.emph("multi class iou:", iou)
