@@ -641,16 +641,24 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     if (with_kn) crf_filter<D>(lt, nullptr, true, lt.norm, lt.kn, true, val0, val1, N, 1, 4, 0, 1, s);
 }
 
-// largest |lattice coordinate| the features can produce: |elevated_j| <= sum_i cf_i + j cf_j, cf_i = fmax_i * scale_i (Permutohedral::init)
+// largest |lattice coordinate| the features can produce.  Permutohedral::init: cf_i = f_i * scale_i and
+//   elevated_j = sum_{i >= j} cf_i - j cf_{j-1}      (elevated_0 = sum_i cf_i, elevated_D = -D cf_{D-1}).
+// The features here are pixel coordinates and colours, i.e. 0 <= f_i <= fmax_i, so the two parts never add up in magnitude:
+//   |elevated_j| <= max(sum_{i >= j} fmax_i scale_i,  j fmax_{j-1} scale_{j-1})
+// (round 4 bounded it by the SUM of the two, which refused 1024-pixel-wide images - 662 against the 512 the 10-bit keys of the bilateral
+// lattice hold - although their coordinates stay below 220; the build kernels check every key they pack as well: flags[2]).
+// + 2 (D + 1) for the rounding to the nearest remainder-0 point and the rank adjustments.
 float crf_key_bound(int D, const float* fmax) {
     const float inv_std_dev = sqrtf(2.0f / 3.0f) * (D + 1);
-    float sum = 0.f, mx = 0.f;
-    for (int i = 0; i < D; ++i) {
-        const float cf = fmax[i] * inv_std_dev / sqrtf((float)((i + 1) * (i + 2)));
-        sum += cf;
-        mx = cf > mx ? cf : mx;
+    float cf[8], tail = 0.f, mx = 0.f;
+    for (int i = 0; i < D; ++i) cf[i] = fmax[i] * inv_std_dev / sqrtf((float)((i + 1) * (i + 2)));
+    for (int j = D; j >= 0; --j) {
+        if (j < D) tail += cf[j];
+        const float neg = j > 0 ? j * cf[j - 1] : 0.f;
+        const float b = tail > neg ? tail : neg;
+        mx = b > mx ? b : mx;
     }
-    return sum + D * mx + 2 * (D + 1);
+    return mx + 2 * (D + 1);
 }
 
 }  // namespace

@@ -253,7 +253,7 @@ def test_crf_oracle_lattice_against_exact_mean_field():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,W,cell,C", [(288, 288, 16, 3), (512, 512, 16, 2), (96, 160, 16, 5)])
+@pytest.mark.parametrize("H,W,cell,C", [(288, 288, 16, 3), (512, 512, 16, 2), (96, 160, 16, 5), (48, 1024, 16, 2)])
 def test_dense_crf_kernels_vs_oracle(H, W, cell, C):
     """simseg_dense_crf (device lattices + mean field) against oracle/crf_ref.py on the reference's parameters: identical labels on
     >= 99.9 % of the pixels of every candidate map, class-1 marginals within 2e-3 on average.  Several candidate maps of one image
