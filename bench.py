@@ -624,6 +624,21 @@ class ClockSampler:
                 "source": getattr(self, "source", None)}
 
 
+def guarded(name, fn, *a, **kw):
+    """A secondary leg must not take the headline down with it: its exception becomes {"error": ...} in the line (and a log entry).  The legs'
+    device work is the same on every rank, so a failure is symmetric and no rank is left waiting in a collective."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:       # noqa: BLE001
+        import traceback
+        log(f"leg {name} FAILED: {e!r}\n{traceback.format_exc()}")
+        try:
+            torch.cuda.synchronize()
+        except Exception:       # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"[:500]}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
     arguments>` - one rank per GPU over RCCL, rendezvous on 127.0.0.1 and a free port (the reference: launch.py:33-70 builds
@@ -674,6 +689,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("SIMSEG_BENCH_DEVICE", os.environ.get("LOCAL_RANK", args.local_rank if args.local_rank is not None else 0)))     # override: bring-up of N ranks on one GPU
+    FULL = world == 1 or os.environ.get("SIMSEG_BENCH_FULL", "0") == "1"       # N > 1: the headline, the other 16-bit type and the sharded evaluation legs only
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with `python bench.py --gpus N`, which starts the N ranks "
                          f"itself, or under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
@@ -830,7 +846,7 @@ def main():
 
     # ---- the same step with the padded caption tokens computed, as HF's BertModel does (secondary figure, same process) ----------
     dense_text = None
-    if os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0":
+    if FULL and os.environ.get("SIMSEG_AMD_PACKED_TEXT", "1") != "0":
         os.environ["SIMSEG_AMD_PACKED_TEXT"] = "0"
         try:
             step()
@@ -857,7 +873,7 @@ def main():
     gelu16 = None
     from simseg_amd import towers as _tw
     compact0 = (_tw._GELU8, _tw._RES16, _tw._XHAT_Y)
-    if any(compact0) and os.environ.get("SIMSEG_BENCH_GELU16_LEG", "1") != "0":
+    if FULL and any(compact0) and os.environ.get("SIMSEG_BENCH_GELU16_LEG", "1") != "0":
         _tw._GELU8 = _tw._RES16 = _tw._XHAT_Y = False
         try:
             for _ in range(2):
@@ -933,20 +949,26 @@ def main():
     del net, model, opt, batches
     torch.cuda.empty_cache()
     seg = None
+    # N > 1 (the driver's scaling runs): the headline, and of the evaluation legs only BASELINE configs[3]'s data-parallel one (source images
+    # sharded over the ranks); the rest is single-GPU material the N = 1 line carries (SIMSEG_BENCH_FULL=1: everything at every N)
     if not args.no_seg:
-        seg = {"fp32": seg_eval_bench(dev, world, "fp32"), "bf16": seg_eval_bench(dev, world, "bf16", windows=256),
-               # the same stage with the reference's DenseCRF in (device mean field on permutohedral lattices, tools/seg_evaluation.py:153)
-               "fp32_crf": seg_eval_bench(dev, world, "fp32", crf=True, steps=1), "bf16_crf": seg_eval_bench(dev, world, "bf16", crf=True, steps=1, windows=256),
-               "vit_s_288_fp32_crf": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
-               # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
-               "vit_s_288_fp32": seg_eval_bench(dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
-               "vit_s_288_bf16": seg_eval_bench(dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
+        seg = {}
+        if FULL:
+            seg = {"fp32": guarded("seg fp32", seg_eval_bench, dev, world, "fp32"), "bf16": guarded("seg bf16", seg_eval_bench, dev, world, "bf16", windows=256),
+                   # the same stage with the reference's DenseCRF in (device mean field on permutohedral lattices, tools/seg_evaluation.py:153)
+                   "fp32_crf": guarded("seg fp32 crf", seg_eval_bench, dev, world, "fp32", crf=True, steps=1),
+                   "bf16_crf": guarded("seg bf16 crf", seg_eval_bench, dev, world, "bf16", crf=True, steps=1, windows=256),
+                   "vit_s_288_fp32_crf": guarded("seg vit-s crf", seg_eval_bench, dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
+                   # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
+                   "vit_s_288_fp32": guarded("seg vit-s fp32", seg_eval_bench, dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
+                   "vit_s_288_bf16": guarded("seg vit-s bf16", seg_eval_bench, dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
         # BASELINE configs[3] proper: 512 x 1024 source images through 3 overlapping windows each, stitched maps, images/s = SOURCE images
-        seg["slide_512x1024"] = {"fp32_crf": seg_slide_bench(dev, world, "fp32", images=21, steps=1, crf=True),
-                                 "bf16_crf": seg_slide_bench(dev, world, "bf16", images=256, steps=1, crf=True, window_batch=256),
-                                 "bf16": seg_slide_bench(dev, world, "bf16", images=256, steps=1, crf=False, window_batch=256),
+        seg["slide_512x1024"] = {"bf16": guarded("slide bf16", seg_slide_bench, dev, world, "bf16", images=256, steps=1, crf=False, window_batch=256),
+                                 "bf16_crf": guarded("slide bf16 crf", seg_slide_bench, dev, world, "bf16", images=256, steps=1, crf=True, window_batch=256),
                                  "images_per_s_is": "source images per second over all ranks (SURVEY.md 8d cfg 4)"}
-        if rank == 0:         # single-image latency (the reference tool's batch size), eager launches vs one hipGraph replay
+        if FULL:
+            seg["slide_512x1024"]["fp32_crf"] = guarded("slide fp32 crf", seg_slide_bench, dev, world, "fp32", images=21, steps=1, crf=True)
+        if rank == 0 and FULL:         # single-image latency (the reference tool's batch size), eager launches vs one hipGraph replay
             seg["latency_batch1"] = [seg_latency_bench(dev, "fp32", 288, 21, "vit_small_patch16_224_in21k", 384),
                                      seg_latency_bench(dev, "fp32", 512, 171, "vit_base_patch16_224_in21k", 768),
                                      seg_latency_bench(dev, "bf16", 512, 171, "vit_base_patch16_224_in21k", 768)]
@@ -955,11 +977,13 @@ def main():
             seg["cpu_baseline"] = cpu_seg
         log(f"seg eval stage: {seg}")
     want_retr = (not args.no_seg) or args.retrieval
-    retr_multi = retrieval_multi_rank_bench(dev, rank, world) if (world > 1 and want_retr) else None       # collective: every rank
-    retr = retrieval_bench(dev) if (rank == 0 and want_retr) else None
-    if retr is not None and retr_multi is not None:
+    retr_multi = guarded("retrieval multi-rank", retrieval_multi_rank_bench, dev, rank, world) if (world > 1 and want_retr and FULL) else None       # collective: every rank
+    retr = retrieval_bench(dev) if (rank == 0 and want_retr and FULL) else None
+    if retr is None and retr_multi is not None and rank == 0:
+        retr = {"multi_rank": retr_multi}
+    elif retr is not None and retr_multi is not None:
         retr["multi_rank"] = retr_multi
-    if retr is not None:
+    if retr is not None and FULL:
         if not args.no_seg:
             retr["encoder_inclusive"] = retrieval_encode_bench(dev)
         if cpu_retr is not None:
