@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"
 from oracle import simseg_ref as R  # noqa: E402
 from simseg_amd.nn import Bert  # noqa: E402
@@ -45,7 +45,7 @@ for (B, L, min_len) in ((6, 77, 8), (6, 25, 3)):
 
 
 # the whole CLIP model as tests/test_gpu_fullsize.py runs it, with the towers on one stream and on two
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from test_gpu_fullsize import _build_vitb  # noqa: E402
 refc = R.init_weights_(R.RefCLIP("vit_base_patch16_224_in21k", "bert-base-uncased", img_size=224), seed=12).eval()
 image = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(21))
