@@ -29,6 +29,67 @@ def test_valid_transforms_resize_normalize():
         build_transforms(cfg, mode="train")        # autoaug etc. are outside the path
 
 
+def _pil_resample_restated(a, H, W, kind):
+    """Pillow's two-pass resampling (ImagingResample: horizontal then vertical, uint8 between the passes; filter support scaled by the
+    reduction factor = its built-in antialiasing) restated with explicit loops: what torchvision's Resize on a PIL image computes
+    (transforms/mml/transforms.py:15-22 -> F.resize -> Image.resize).  triangle filter = BILINEAR, Keys cubic a = -0.5 = BICUBIC."""
+    def tri(x):
+        x = abs(x)
+        return 1 - x if x < 1 else 0.0
+
+    def cubic(x, A=-0.5):
+        x = abs(x)
+        if x < 1:
+            return ((A + 2) * x - (A + 3)) * x * x + 1
+        if x < 2:
+            return (((x - 5) * x + 8) * x - 4) * A
+        return 0.0
+
+    flt, sup = (tri, 1.0) if kind == "bilinear" else (cubic, 2.0)
+
+    def one_axis(arr, out_size, axis):
+        in_size = arr.shape[axis]
+        scale = in_size / out_size
+        fs = max(scale, 1.0)
+        support = sup * fs
+        arr = np.moveaxis(arr, axis, 0).astype(np.float64)
+        out = np.zeros((out_size,) + arr.shape[1:])
+        for i in range(out_size):
+            c = (i + 0.5) * scale
+            lo, hi = max(int(c - support + 0.5), 0), min(int(c + support + 0.5), in_size)
+            w = np.array([flt((j + 0.5 - c) / fs) for j in range(lo, hi)])
+            out[i] = np.tensordot(w / w.sum(), arr[lo:hi], 1)
+        return np.clip(np.rint(np.moveaxis(out, 0, axis)), 0, 255)
+
+    return one_axis(one_axis(a, W, 1), H, 0).astype(np.uint8)
+
+
+def test_resize_interpolation_arithmetic_and_crop_geometry():
+    """The interpolation arithmetic of the valid transforms on a NON-constant image (round 4's test used a constant one): `resize` (square,
+    bilinear, down- and up-sampling), `resize_bicubic` (shorter side -> size, aspect kept, rounding of the longer side as torchvision
+    computes it) and `center_crop` (torchvision's rounding of the offsets), against the restated Pillow resampler - within 1 grey level
+    (Pillow accumulates in fixed point, the restatement in float64)."""
+    from simseg.transforms import TRANSFORMS
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    img = Image.fromarray(a)
+    for size in (24, 64):
+        out = np.asarray(TRANSFORMS.get("resize")(_cfg([f"transforms.resize.size={size}"]))(img))
+        ref = _pil_resample_restated(a, size, size, "bilinear")
+        assert out.shape == (size, size, 3) and int(np.abs(out.astype(int) - ref.astype(int)).max()) <= 1
+        assert float((out != ref).mean()) < 0.05
+    for size, hw in ((24, (24, 34)), (74, (74, 106))):                   # 37 x 53: the shorter side is the height; 53 * size / 37 rounded
+        out = np.asarray(TRANSFORMS.get("resize_bicubic")(_cfg([f"transforms.resize_bicubic.size={size}"]))(img))
+        assert out.shape[:2] == hw
+        ref = _pil_resample_restated(a, hw[0], hw[1], "bicubic")
+        assert int(np.abs(out.astype(int) - ref.astype(int)).max()) <= 1
+    tall = Image.fromarray(np.ascontiguousarray(a.transpose(1, 0, 2)))    # 53 x 37: now the width is the shorter side
+    assert np.asarray(TRANSFORMS.get("resize_bicubic")(_cfg(["transforms.resize_bicubic.size=24"]))(tall)).shape[:2] == (34, 24)
+    crop = np.asarray(TRANSFORMS.get("center_crop")(_cfg(["transforms.center_crop.size=20"]))(img))
+    top, left = int(round((37 - 20) / 2.0)), int(round((53 - 20) / 2.0))
+    np.testing.assert_array_equal(crop, a[top:top + 20, left:left + 20])
+
+
 def test_seg_loader_layouts(tmp_path):
     from simseg.datasets.seg.seg_dataset import build_torch_valid_loader
     root = tmp_path / "VOCdevkit" / "VOC2012"
