@@ -134,9 +134,6 @@ int simseg_debug_gemm_stagger(int ticks);
 /* debug / experiments (thread-local): > 0 = the split-K weight-gradient GEMMs (transA, fp32 accumulate) use at most this many 256x256
  * blocks, i.e. CUs, instead of one round of all of them; 0 = default. */
 int simseg_debug_gemm_wgrad_blocks(int blocks);
-/* experiments (thread-local): tile order of the persistent 256x256 GEMM - column tiles per group (group-major order keeps a group's slice
- * of B in the XCD's L2); -1 = chosen per shape from an L2-fill estimate (default), 0 = row-major over all columns (rounds 3-4), > 0 forced. */
-int simseg_debug_gemm_colgroup(int g);
 
 /* Fused softmax attention, head_dim 64, from the packed projection qkv[B,T,3,H,64] to ctx[B,T,H*64].
  * key_mask[B,T] (1 = attend, 0 = padding; may be NULL) reproduces HF's additive key-padding mask; lse[B,H,T]

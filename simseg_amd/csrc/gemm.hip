@@ -61,7 +61,6 @@ struct GemmParams {
     int res_mod;             // residual row = 1 + r % G (pos_embed) instead of the output row
     int accumulate;          // C += result (fp32 output only; always set when split-K)
     unsigned long long* dbg_trace;   // debugging only (simseg_debug_gemm_trace): per block {start, K loop start, K loop end, end} wall-clock stamps + hardware id
-    int colgroup;            // persistent ping-pong kernel: column tiles per group of its tile order (0 / >= tiles_n: row-major over all columns); see pp2_item
     int stagger;             // ping-pong kernel: first-round blocks start (slot % 4) * stagger wall-clock ticks (10 ns) late (see launch_pp)
     int dbg_skip_epilogue;   // benchmarking only (simseg_set_gemm_variant(100 + v)): the accumulators are kept live but nothing is stored
     int ksplit;              // k-tiles per split-K slice
@@ -1503,26 +1502,11 @@ __device__ __forceinline__ unsigned pp2_lane_off(int piece, int lane, long ld) {
 
 struct PP2Item { int m0, n0, ntile; const char* a0; const char* b0; };
 
-// Tile order of the persistent kernel (round 5).  The tile list is cut into 8 contiguous chunks, one per XCD, and an XCD's 32 workgroups
-// walk theirs 32 consecutive tiles at a time.  Row-major over ALL column tiles, those 32 tiles touch the whole B operand every round:
-// with a weight matrix that does not fit the XCD's 4 MB L2 beside the A panels in flight (768 x 3072: 4.7 MB) every round re-fetches it
-// through the fabric - measured 1025 MB of L2 fills for the 155 + 5 MB the fc1 forward reads (rocprofv3 FETCH_SIZE per shape,
-// profiles/r5_gemm_fabric_traffic.txt).  With column GROUPS (p.colgroup tiles wide: group-major, then row panels, then the group's
-// columns) an XCD stays inside one group for its whole chunk: that group's slice of B stays in L2 and A is read once per group.
 template <bool TA, bool TB>
 __device__ __forceinline__ PP2Item pp2_item(const GemmParams& p, int t, int tiles_n) {
     PP2Item it;
-    const int G = p.colgroup;
-    if (G <= 0 || G >= tiles_n) {
-        it.m0 = (t / tiles_n) << 8;
-        it.n0 = (t % tiles_n) << 8;
-    } else {
-        const int per = G * (p.M >> 8);                              // tiles of a full group
-        const int g = t / per, r = t - g * per;
-        const int gw = min(G, tiles_n - g * G);                       // (the last group may be narrower)
-        it.m0 = (r / gw) << 8;
-        it.n0 = (g * G + r % gw) << 8;
-    }
+    it.m0 = (t / tiles_n) << 8;
+    it.n0 = (t % tiles_n) << 8;
     it.ntile = p.K >> 6;
     it.a0 = static_cast<const char*>(p.A) + (TA ? (long)it.m0 * 2 : (long)it.m0 * p.lda * 2);
     it.b0 = static_cast<const char*>(p.B) + (TB ? (long)it.n0 * 2 : (long)it.n0 * p.ldb * 2);
@@ -1717,32 +1701,6 @@ bool pp2_ok(const GemmParams& p, int splitk) {
     return !p.aux && p.act == 0 && !p.colsum && !p.accumulate;
 }
 
-// Column tiles per group of the persistent kernel's tile order (pp2_item): estimated L2-fill traffic of both orders, from the model the
-// per-shape FETCH_SIZE measurements follow - row-major: A once + B once per XCD per round of 32 tiles when B and the A panels in flight
-// overflow the 4 MB L2; grouped: A once per group + each group's B slice once per XCD that works in it.  -1 = auto, 0 = off, > 0 = forced
-// (simseg_debug_gemm_colgroup).
-thread_local int g_gemm_colgroup = -1;
-inline int pp2_colgroup(const GemmParams& p) {
-    const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
-    if (g_gemm_colgroup >= 0) return g_gemm_colgroup;
-    if (tiles_n < 2 || tiles_m < 64) return 0;
-    const double a_bytes = 2.0 * p.M * p.K, b_bytes = 2.0 * p.N * p.K, col_bytes = 2.0 * 256 * p.K, l2 = 4.0 * 1024 * 1024;
-    const double panels_in_flight = 32.0 / tiles_n < 1.0 ? 1.0 : 32.0 / tiles_n;
-    if (b_bytes + panels_in_flight * col_bytes <= 0.9 * l2) return 0;             // everything of a round fits: B stays resident as it is
-    const double rounds = (double)tiles_m * tiles_n / 8.0 / 32.0;
-    const double est_now = a_bytes + rounds * b_bytes * 8.0;
-    int best = 0;
-    double best_est = est_now * 0.8;                                              // (regroup only for a clear gain)
-    for (int ng = 2; ng <= tiles_n; ++ng) {
-        const int G = (tiles_n + ng - 1) / ng;
-        if ((double)G * col_bytes > 0.6 * l2) continue;                           // the group's B slice must stay in L2 beside the streaming A
-        const double est = a_bytes * ng + 8.0 * b_bytes / ng;
-        if (est < best_est) { best_est = est; best = G; }
-        break;                                                                     // the fewest groups whose slice fits: A is read once per group
-    }
-    return best;
-}
-
 template <typename TO, bool TA, bool TB, int SCHED = 0, int EK = 1>
 int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
     constexpr int SMEM = 9 * PP_HALF;
@@ -1760,7 +1718,6 @@ int launch_pp2(const GemmParams& p, hipStream_t stream, int reserve = 0) {
     }
     GemmParams q = p;
     q.ksplit = p.K / 64; q.nsplit = 1;
-    q.colgroup = pp2_colgroup(p);
     // reserve > 0 (variant 18): that many CUs are left to the kernels of the other stream - a persistent launch never hands a CU back, so
     // without a reserve the other tower's kernels wait for whole GEMM launches (the -6.7 % of round 3's first half)
     const int nb = reserve > 0 ? ((blocks - reserve) & ~7) : blocks;
@@ -2069,13 +2026,6 @@ extern "C" int simseg_debug_gemm_wgrad_blocks(int blocks) {
     simseg_debug_gemm_wgrad_blocks_h16(blocks);
 #endif
     g_gemm_wgrad_blocks = blocks;
-    return 0;
-}
-extern "C" int simseg_debug_gemm_colgroup(int g) {
-#ifndef SS_HALF
-    simseg_debug_gemm_colgroup_h16(g);
-#endif
-    g_gemm_colgroup = g;
     return 0;
 }
 extern "C" int simseg_debug_gemm_trace(void* buf) { g_gemm_debug_trace = static_cast<unsigned long long*>(buf); return 0; }

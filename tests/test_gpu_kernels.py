@@ -301,42 +301,6 @@ def test_gemm_bf16_splitk_and_dgelu(ops):
     _close(ops.gemm(a, w, trans_b=True, act=2, aux=pre), (a.float() @ w.float()) * x32.grad, 1e-2, "dgelu")
 
 
-@pytest.mark.parametrize("kind", ["nt", "nn"])
-def test_persistent_gemm_column_group_tile_order_is_bit_equal(ops, kind):
-    """Round 5: the persistent 256x256 kernel walks its tiles column-group-major (simseg_debug_gemm_colgroup; chosen per shape from an
-    L2-fill estimate).  The order changes which workgroup computes which tile and nothing else: every forced group width - incl. widths
-    that leave a narrower last group and the automatic choice - gives the bits of the row-major order, with and without the fc1 epilogue that
-    writes the tile-blocked derivative image."""
-    from simseg_amd.lib import call, raw
-    M, N, K = 64 * 256, 9 * 256, 256
-    a = _rand(M, K, seed=1, dtype=torch.bfloat16)
-    b = _rand(N, K, seed=2, dtype=torch.bfloat16) if kind == "nt" else _rand(K, N, seed=2, dtype=torch.bfloat16)
-    bias = _rand(N, seed=3)
-
-    def run(g):
-        call("simseg_debug_gemm_colgroup", g)
-        try:
-            y = ops.gemm(a, b, trans_b=(kind == "nn"), out_dtype=torch.bfloat16)
-            out = [y]
-            if kind == "nt" and ops.gemm_aux_blocked_ok(M, N, K):
-                aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-                out += [ops.gemm(a, b, bias=bias, act=5, aux_out=aux, out_dtype=torch.bfloat16), aux]
-            out.append(raw("simseg_gemm_last_variant"))
-            return out
-        finally:
-            call("simseg_debug_gemm_colgroup", -1)
-
-    want = run(0)
-    assert want[-1] == 10, "the shape must run on the persistent kernel (variant code 10)"
-    want = want[:-1]
-    ref = a.float() @ (b.float().t() if kind == "nt" else b.float())
-    _close(want[0], ref, 2e-2, "persistent gemm")
-    for g in (1, 2, 4, 5, 8, -1):
-        got = run(g)[:-1]
-        for x, y in zip(got, want):
-            assert torch.equal(x, y), (kind, g)
-
-
 def test_gemm_dropout_epilogue(ops):
     a, b = _rand(512, 64, seed=1), _rand(256, 64, seed=2)
     y0 = ops.gemm(a, b)

@@ -6,6 +6,23 @@ import sqlite3
 import sys
 
 
+def runs(path, pat, n):
+    """Consecutive dispatches of the matching kernels in groups of n (tools/gemm_bench.py launches every shape 3 + iters times in a row)."""
+    c = sqlite3.connect(path)
+    tables = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    t = lambda p: next(x for x in tables if x.startswith(p))      # noqa: E731
+    disp, sym, pmc, info = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol"), t("rocpd_pmc_event"), t("rocpd_info_pmc")
+    scols = [r[1] for r in c.execute(f"pragma table_info({sym})")]
+    name_col = "kernel_name" if "kernel_name" in scols else "display_name"
+    q = (f"select s.{name_col}, i.name, p.value, d.start, d.end - d.start from {pmc} p join {disp} d on p.event_id = d.event_id "
+         f"join {sym} s on d.kernel_id = s.id join {info} i on p.pmc_id = i.id order by d.start")
+    rows = [(re.sub(r"\(.*", "", k), cn, v, dur) for k, cn, v, st, dur in c.execute(q) if pat in k]
+    for g in range(0, len(rows), n):
+        part = rows[g:g + n]
+        print(f"run {g // n:3d}  {part[0][0][20:80]:60s} {part[0][1]:<11} avg {sum(r[2] for r in part) / len(part):12.1f} KB  x2 = "
+              f"{2 * 1024 * sum(r[2] for r in part) / len(part) / 1e6:8.1f} MB  avg_us {sum(r[3] for r in part) / len(part) / 1e3:8.1f}")
+
+
 def main(path, pat=""):
     c = sqlite3.connect(path)
     tables = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -29,4 +46,7 @@ def main(path, pat=""):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    if len(sys.argv) > 3:
+        runs(sys.argv[1], sys.argv[2], int(sys.argv[3]))
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
