@@ -33,7 +33,7 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-TRAFFIC_JSON = "r4_pmc_traffic.json"
+TRAFFIC_JSON = "r5_pmc_traffic.json"
 
 
 def git_blob_sha1(path):

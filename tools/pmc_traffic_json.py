@@ -17,6 +17,7 @@ def parse(path, counter):
 
 
 def kind_of(name):
+    name = name.replace("DF16_", "DF16b")          # the fp16 flavour's mangled 16-bit type (the headline arithmetic since round 5)
     m = re.search(r"gemm_kernelI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)E", name)
     suffix = ""
     if not m:
@@ -49,7 +50,7 @@ def main(prefix="profiles/r1"):
         commit = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         commit = None
-    json.dump({"commit": commit, "gemm_hip_blob": blob, "command": "SIMSEG_AMD_TWO_STREAMS=0 rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-seg",
+    json.dump({"commit": commit, "gemm_hip_blob": blob, "command": "SIMSEG_BENCH_FP16=0 SIMSEG_AMD_TWO_STREAMS=0 rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-seg  (the fp16 headline arithmetic; tools/profile_round.sh)",
                "note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
                        "wide coalesced read); WRITE_SIZE is uncalibrated there", "per_kind": res}, open(prefix + "_pmc_traffic.json", "w"), indent=1)
     for k, v in sorted(res.items()):
