@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def parse_args():
     ap = argparse.ArgumentParser(description="SimSeg zero-shot segmentation evaluation (device post-processing)")
     ap.add_argument("--cfg", required=True)
-    ap.add_argument("--local_rank", type=int, default=0)
+    ap.add_argument("--local_rank", "--local-rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))      # (torch.distributed.run sets LOCAL_RANK; torch.distributed.launch passes the flag)
     ap.add_argument("--ckpt_path", default="")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate N synthetic images with random weights")
