@@ -385,10 +385,16 @@ __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < CS; ++c) acc[c] += w * ((extra && c == C) ? 1.0f : v[c]);
         }
+        // the group's partial sums meet through the DPP network (round 5; was a ds_bpermute tree: 3-4 LDS-crossbar round trips per channel):
+        // quad butterflies, then the half-row mirror (8 lanes) and, for 16-lane groups, the row mirror - every lane of the group ends with the sum
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
-#pragma unroll
-            for (int o = G / 2; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+#define CRF_DPP_ADD(ctrl) acc[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[c]), ctrl, 0xf, 0xf, true))
+            CRF_DPP_ADD(0xB1);                        // quad_perm [1,0,3,2]
+            CRF_DPP_ADD(0x4E);                        // quad_perm [2,3,0,1]
+            CRF_DPP_ADD(0x141);                       // row_half_mirror: lanes i <-> 7 - i of every 8
+            if (G == 16) CRF_DPP_ADD(0x140);          // row_mirror: lanes i <-> 15 - i of every 16
+#undef CRF_DPP_ADD
         }
         if (live && sub == 0) {
 #pragma unroll
