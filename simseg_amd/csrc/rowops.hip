@@ -797,20 +797,32 @@ inline int grid_for(long n, int block, int cap = 4096) {
 // were resident and a quarter-full second round followed.
 constexpr int LN_BWD_MAX_GRID = 2048;
 inline int ln_bwd_grid(const void* fn, int slot, size_t lds, long rows) {
-    static int cached[32];           // blocks per device for instantiation `slot` (0 = not asked yet)
+    // (one process drives one GPU; a benign race between host threads costs a repeated query, never a wrong grid: every value written is valid)
+    static int ncu = 0;              // CUs of the device, asked once (hipGetDeviceProperties is a millisecond-class call)
+    static int cached[32];           // blocks per CU of instantiation `slot` at LDS size cached_lds[slot] (0 = not asked yet)
     static size_t cached_lds[32];
-    int per_dev = (slot >= 0 && slot < 32 && cached_lds[slot] == lds) ? cached[slot] : 0;
-    if (per_dev <= 0) {
-        int per_cu = 0, dev = 0, ncu = 256;
+    static int forced = -1;          // SIMSEG_LN_BWD_BLOCKS_PER_CU (tools/ln_bench.py sweeps), read once
+    if (ncu <= 0) {
+        int dev = 0, n = 256;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
-        if (const char* e = getenv("SIMSEG_LN_BWD_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }     // (tools/ln_bench.py sweeps)
-        per_dev = per_cu * ncu;
-        if (slot >= 0 && slot < 32) { cached[slot] = per_dev; cached_lds[slot] = lds; }
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        ncu = n;
     }
+    if (forced < 0) {
+        const char* e = getenv("SIMSEG_LN_BWD_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        forced = v > 0 ? v : 0;
+    }
+    const bool ok = slot >= 0 && slot < 32;
+    int per_cu = (ok && cached_lds[slot] == lds) ? cached[slot] : 0;
+    if (per_cu <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
+        if (ok) { cached[slot] = per_cu; cached_lds[slot] = lds; }
+    }
+    if (forced > 0) per_cu = forced;
+    const long per_dev = (long)per_cu * ncu;
     const int want = grid_for(rows, 4, LN_BWD_MAX_GRID);
-    return want < per_dev ? want : per_dev;
+    return want < per_dev ? want : (int)per_dev;
 }
 
 

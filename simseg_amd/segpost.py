@@ -185,7 +185,9 @@ def evaluate_sharded(model, batches, text, top_cls_num, num_classes=None, group=
     every rank - data-parallel over the ranks of `group` (default: the world, or a single process when torch.distributed is not
     initialised): batches are dealt round-robin (shard_batches; the reference's loader gives every rank every image,
     simseg/datasets/seg/seg_dataset.py:67-81), each rank accumulates its [3, C] area histograms on its device and ONE all-reduce(SUM) of that
-    tensor ends the evaluation (simseg/utils/metrics.py:85-97 sums the same three vectors over the images).  slide = (win, stride): the
+    tensor ends the evaluation (simseg/utils/metrics.py:85-97 sums the same three vectors over the images).  Every rank still ITERATES the
+    whole iterable (a batch it skips is produced and dropped): hand in something cheap to iterate - batch descriptors, or a loader over a
+    dataset sharded with the same i % world == rank rule - when producing a batch is expensive.  slide = (win, stride): the
     sliding-window form (encode_batch_sliding); None: one network input per image (encode_batch).
     -> dict(iou [C] float64, miou, hist [3,C] int64 (global), images (global count), images_local)."""
     import torch.distributed as dist
