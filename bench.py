@@ -551,6 +551,39 @@ def attention_roofline(dev, B, img, L, H=12, reps=10, dtype=torch.bfloat16):
     return out
 
 
+def layernorm_roofline(dev, B, img, D=768, reps=10, dtype=torch.bfloat16):
+    """The LayerNorm kernels of the ViT blocks, each timed alone on the step's shape ([B * T, D]), in the forms the 16-bit step runs: forward
+    fp32 -> 16-bit (6 bytes per element) and backward dy16 + y16 + dres16 -> dx16 (8 bytes per element, ln_bwd16_kernel + its column reduce)."""
+    from simseg_amd import ops
+    T = 1 + (img // 16) ** 2
+    M = B * T
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(M, D, device=dev, generator=g)
+    w, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y, _, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-6, out_dtype=dtype, save_stats=True)
+    dy, dres = torch.randn(M, D, device=dev, generator=g).to(dtype), torch.randn(M, D, device=dev, generator=g).to(dtype)
+    dg, db, ds = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    tf = timed(lambda: ops.layernorm_fwd(x, w, b, 1e-6, out_dtype=dtype, save_stats=True))
+    tb = timed(lambda: ops.layernorm_bwd(x, mean, rstd, w, dg, db, dy16=dy, dres16=dres, dxsum=ds, want_f32=False, y16=y, beta=b))
+    out = {}
+    for tag, sec, by in (("fwd", tf, 6.0 * M * D), ("bwd", tb, 8.0 * M * D)):
+        out[f"layernorm_vit_{tag}"] = {"shape": f"[{M}, {D}]", "ms": round(sec * 1e3, 4), "bound": "hbm", "GBps": round(by / sec / 1e9, 1),
+                                       "frac_of_hbm_peak": round(by / sec / 8e12, 4), "launches_per_step": 25 if tag == "fwd" else 24}
+    return out
+
+
 class ClockSampler:
     """Shader clock and package power during the timed region (rocm-smi polled from a side thread; host-side only).  MI355X is
     power-capped under matrix-core load: the dense peaks of MI355X_MICROARCH.md assume 2.4 GHz, the step runs at ~1.9 GHz / ~1.36 kW,
@@ -945,6 +978,8 @@ def main():
         a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
     ops.PROFILE = None
     attn_roofline = attention_roofline(dev, B, args.img, L, dtype=HALF[HEAD]) if rank == 0 else {}
+    if rank == 0:
+        attn_roofline.update(guarded("layernorm roofline", layernorm_roofline, dev, B, args.img, dim, dtype=HALF[HEAD]) or {})
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"          # (the evaluation legs below choose their own type)
     del net, model, opt, batches
     torch.cuda.empty_cache()
