@@ -223,17 +223,14 @@ __global__ __launch_bounds__(256) void crf_simplex_kernel(const unsigned char* _
 // Every lattice point draws a dense id, in the order of the (pixel, vertex) entries that CREATED the points (bit 31 of off[]): points
 // are then numbered along the image raster, so the value rows a pixel's slice reads, the pixels a point's gather reads and most blur
 // neighbours lie close together in memory (numbering in hash-slot order scattered all three over the whole array).  A thread looks at
-// 16 consecutive entries, a wave draws ONE range from the counter (prefix sums inside the wave; a per-entry atomicAdd on the single
-// counter word serialises millions of same-address atomics).
-__global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__ off, long nv, const unsigned long long* __restrict__ hkeys,
-                                                         int* __restrict__ hid, unsigned long long* __restrict__ pkeys, int* __restrict__ M) {
-    // (one range per BLOCK, not per wave: the counter is a single word and same-address atomics serialise - 24 k of them were most of this
-    // kernel's 124 us per 16-image lattice)
-    __shared__ int wsum[4];
-    __shared__ int bbase;
-    const long e0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
-    int slots[16];
-    int n = 0;
+// 16 consecutive entries.
+// Round 5: the ids are EXACTLY in entry order - a count pass, an exclusive scan of the per-block totals and the assignment proper.  Rounds 2-4
+// let every block draw its range from one atomic counter: blocks reach it in the order they happen to run, ~2000 of them (5 images' worth of
+// pixels) in flight at any time, so ids 200 apart could lie images apart and a contiguous run of points touched pixels all over a
+// 20 MB window - the gather's value reads missed L2 for 57 % of their requests (2.6 GB of fills per filter for 0.57 GB of operands,
+// profiles/r5_crf_pmc.txt).  The numbering is now deterministic as well (the lattice no longer depends on scheduling).
+__device__ __forceinline__ int crf_assign_local(const int* __restrict__ off, long nv, long e0, int (&slots)[16], int* wsum, int& n) {
+    n = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         slots[j] = e0 + j < nv ? off[e0 + j] : 0;
@@ -245,15 +242,42 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__
         const int t = __shfl_up(incl, o, 64);
         if ((int)(threadIdx.x & 63) >= o) incl += t;
     }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) wsum[w] = incl;
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        bbase = tot ? atomicAdd(M, tot) : 0;
+    return incl;
+}
+__global__ __launch_bounds__(256) void crf_assign_count_kernel(const int* __restrict__ off, long nv, int* __restrict__ btot) {
+    __shared__ int wsum[4];
+    int slots[16], n;
+    crf_assign_local(off, nv, ((long)blockIdx.x * 256 + threadIdx.x) * 16, slots, wsum, n);
+    if (threadIdx.x == 0) btot[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// exclusive scan of the per-block totals in place (one block; a 32-image bilateral lattice has ~12 k blocks), total -> *M
+__global__ __launch_bounds__(1024) void crf_assign_scan_kernel(int* __restrict__ btot, int nb, int* __restrict__ M) {
+    __shared__ int part[1024];
+    const int per = (nb + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += btot[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                           // Hillis-Steele over the 1024 partial sums
+        const int t = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
     }
-    __syncthreads();
-    int id = bbase + incl - n;
+    int run = part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) { const int c = btot[b]; btot[b] = run; run += c; }
+    if (threadIdx.x == 1023) *M = part[1023];
+}
+__global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__ off, long nv, const unsigned long long* __restrict__ hkeys,
+                                                         int* __restrict__ hid, unsigned long long* __restrict__ pkeys, const int* __restrict__ bbase) {
+    __shared__ int wsum[4];
+    int slots[16], n;
+    const int incl = crf_assign_local(off, nv, ((long)blockIdx.x * 256 + threadIdx.x) * 16, slots, wsum, n);
+    const int w = threadIdx.x >> 6;
+    int id = bbase[blockIdx.x] + incl - n;
     for (int k = 0; k < w; ++k) id += wsum[k];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -362,28 +386,49 @@ __global__ __launch_bounds__(256) void crf_gather_kernel(const float* __restrict
     if (in) in += (long)blockIdx.y * in_stride;                   // blockIdx.y: images that SHARE this lattice (the spatial one), see crf_filter
     val += (long)blockIdx.y * val_stride;
     const long Mr = ((long)*M + 256 / G - 1) / (256 / G) * (256 / G);            // whole groups stay together through the shuffles
-    for (long m = ((long)blockIdx.x * 256 + threadIdx.x) / G; m < Mr; m += (long)gridDim.x * (256 / G)) {
+    // Block -> point map (round 5): every block owns ONE contiguous run of points, and the blocks of an XCD (blockIdx % 8, xcd_remap) own
+    // neighbouring runs.  Point ids follow the tile-major pixel raster, and a pixel's value row is read through up to d + 1 points with
+    // nearby ids: with a grid-stride map those reads were spread over all eight XCDs' L2s (each a miss of its own: 128-byte fills for 16
+    // useful bytes); now they meet in one L2.
+    constexpr int PPB = 256 / G;                                  // points per block and trip
+    const long trips = (Mr / PPB + gridDim.x - 1) / gridDim.x;    // trips of every block over its run
+    const long run0 = (long)xcd_remap(blockIdx.x, gridDim.x) * trips * PPB;
+    for (long t = 0, m = run0 + threadIdx.x / G; t < trips && m < Mr; ++t, m += PPB) {
         float acc[CS];
 #pragma unroll
         for (int c = 0; c < CS; ++c) acc[c] = 0.f;
         const bool live = m < *M;
         const int s0 = live ? start[m] : 0, n = live ? cnt[m] : 0;
-        for (int j = sub; j < n; j += G) {
-            const int2 r = rec[s0 + j];
-            const float w = __int_as_float(r.y);
-            float v[CS];
-            if (in) {
+        // U entries per lane and trip, every record requested before the first value, every value before the first use: a list of up to
+        // U * G entries (the typical bilateral point has 10-25) costs two memory round trips instead of two per entry of a lane (round 5)
+        constexpr int U = CS == 4 ? 4 : 2;
+        for (int j0 = sub; j0 < n; j0 += U * G) {
+            int2 r[U];
 #pragma unroll
-                for (int q = 0; q < CS / 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(in + (long)r.x * CS + 4 * q);
-                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * G;
+                r[u] = j < n ? rec[s0 + j] : make_int2(0, 0);            // weight 0: the entry contributes nothing (pixel 0 is a valid address)
+            }
+            float v[U][CS];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (in) {
+#pragma unroll
+                    for (int q = 0; q < CS / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4*>(in + (long)r[u].x * CS + 4 * q);
+                        v[u][4 * q] = t.x; v[u][4 * q + 1] = t.y; v[u][4 * q + 2] = t.z; v[u][4 * q + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) v[u][c] = 1.0f;
                 }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CS; ++c) v[c] = 1.0f;
             }
 #pragma unroll
-            for (int c = 0; c < CS; ++c) acc[c] += w * ((extra && c == C) ? 1.0f : v[c]);
+            for (int u = 0; u < U; ++u) {
+                const float w = __int_as_float(r[u].y);
+#pragma unroll
+                for (int c = 0; c < CS; ++c) acc[c] += w * ((extra && c == C) ? 1.0f : v[u][c]);
+            }
         }
         // the group's partial sums meet through the DPP network (round 5; was a ds_bpermute tree: 3-4 LDS-crossbar round trips per channel):
         // quad butterflies, then the half-row mirror (8 lanes) and, for 16-lane groups, the row mirror - every lane of the group ends with the sum
@@ -426,9 +471,22 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long 
 #pragma unroll
             for (int k = 0; k < D; ++k) { k1[k] = key[k] - 1; k2[k] = key[k] + 1; }
             if (j < D) { k1[j] = key[j] + D; k2[j] = key[j] - D; }
-            nb[((long)j * mmax + i) * 2 + 0] = crf_find(table, crf_pack<D>(k1, img));
-            nb[((long)j * mmax + i) * 2 + 1] = crf_find(table, crf_pack<D>(k2, img));
+            // The two neighbours along an axis are each other's inverse (k2 of k1(i) is i): ONE hash search per point and axis, the found
+            // point gets this one as its "minus" neighbour by a plain store (round 5; was two searches: 12 instead of 6 scattered probe
+            // chains per point of the bilateral lattice, 68 M L2 misses per build).  crf_neighbors_init_kernel has set every "minus"
+            // entry to -1 = "missing" beforehand.
+            (void)k2;
+            const int pn = crf_find(table, crf_pack<D>(k1, img));
+            nb[((long)j * mmax + i) * 2 + 0] = pn;
+            if (pn >= 0) nb[((long)j * mmax + pn) * 2 + 1] = (int)i;
         }
+    }
+}
+__global__ __launch_bounds__(256) void crf_neighbors_init_kernel(const int* __restrict__ M, int* __restrict__ nb, long mmax, int d1) {
+    const long total = (long)*M * d1;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long j = t / *M, i = t - j * *M;
+        nb[(j * mmax + i) * 2 + 1] = -1;
     }
 }
 
@@ -634,7 +692,13 @@ void crf_build(const CrfLattice& lt, const unsigned char* rgb, int nimg, int H, 
     const CrfTable table{lt.hkeys, lt.hid, (unsigned)(lt.scap - 1), (unsigned)(lt.cap - 1)};
     hipLaunchKernelGGL(crf_simplex_kernel<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rgb, nimg, H, W, tw, 1.0f / sxy, 1.0f / srgb, table,
                        lt.off, lt.bary, overflow);
-    hipLaunchKernelGGL(crf_assign_kernel, dim3((unsigned)((nv + 4095) / 4096)), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.M);
+    {   // dense point ids in entry order: count, scan, assign (the per-block totals borrow the head of lt.cnt, which is zeroed afterwards)
+        const unsigned nb = (unsigned)((nv + 4095) / 4096);
+        hipLaunchKernelGGL(crf_assign_count_kernel, dim3(nb), dim3(256), 0, s, lt.off, nv, lt.cnt);
+        hipLaunchKernelGGL(crf_assign_scan_kernel, dim3(1), dim3(1024), 0, s, lt.cnt, (int)nb, lt.M);
+        hipLaunchKernelGGL(crf_assign_kernel, dim3(nb), dim3(256), 0, s, lt.off, nv, lt.hkeys, lt.hid, lt.pkeys, lt.cnt);
+    }
+    hipLaunchKernelGGL(crf_neighbors_init_kernel, dim3(crf_blocks(N / 4 * (D + 1))), dim3(256), 0, s, lt.M, lt.nb, lt.mmax, D + 1);
     hipLaunchKernelGGL(crf_neighbors_kernel<D>, dim3(crf_blocks(N / 4)), dim3(256), 0, s, lt.pkeys, lt.M, table, lt.nb, lt.mmax);
     (void)hipMemsetAsync(lt.cnt, 0, (size_t)nv * sizeof(int), s);
     hipLaunchKernelGGL(crf_count_kernel, dim3((unsigned)((nv + 1023) / 1024)), dim3(256), 0, s, lt.off, lt.hid, lt.cnt, lt.cnt + nv, nv);
