@@ -296,8 +296,11 @@ __global__ __launch_bounds__(256) void crf_assign_kernel(const int* __restrict__
 // (hid: the entries still hold hash slots when this kernel starts - translated to dense point ids here, on the way)
 __global__ __launch_bounds__(256) void crf_count_kernel(int* __restrict__ off, const int* __restrict__ hid, int* __restrict__ cnt, int* __restrict__ rank,
                                                         long nv) {
+    // Round 5: the block's table is keyed by the HASH SLOT an entry still holds, and the slot -> dense id translation (a 4-byte read at a
+    // random place of the hash-sized id array: a 128-byte L2 fill each) is made once per DISTINCT slot of the block instead of once per
+    // entry - a block's 1024 entries hold a few hundred distinct points.
     constexpr int LSLOTS = 2048, EPT = 4;
-    __shared__ int lid[LSLOTS], lcnt[LSLOTS], lbase[LSLOTS];
+    __shared__ int lid[LSLOTS], lcnt[LSLOTS], lbase[LSLOTS], lm[LSLOTS];
     for (int t = threadIdx.x; t < LSLOTS; t += 256) { lid[t] = -1; lcnt[t] = 0; }
     __syncthreads();
     const long e0 = (long)blockIdx.x * (256 * EPT) + threadIdx.x;
@@ -307,12 +310,11 @@ __global__ __launch_bounds__(256) void crf_count_kernel(int* __restrict__ off, c
         const long e = e0 + 256 * j;
         slot[j] = -1;
         if (e < nv) {
-            const int m = hid[off[e] & 0x7fffffff];
-            off[e] = m;
-            unsigned sl = ((unsigned)m * 0x9E3779B1u) >> 21;      // 11 bits
+            const int hs = off[e] & 0x7fffffff;                   // global hash slot of the entry's point
+            unsigned sl = ((unsigned)hs * 0x9E3779B1u) >> 21;      // 11 bits
             for (;;) {
-                const int prev = atomicCAS(&lid[sl], -1, m);
-                if (prev == -1 || prev == m) break;
+                const int prev = atomicCAS(&lid[sl], -1, hs);
+                if (prev == -1 || prev == hs) break;
                 sl = (sl + 1) & (LSLOTS - 1);
             }
             slot[j] = (int)sl;
@@ -321,11 +323,18 @@ __global__ __launch_bounds__(256) void crf_count_kernel(int* __restrict__ off, c
     }
     __syncthreads();
     for (int t = threadIdx.x; t < LSLOTS; t += 256)
-        if (lid[t] >= 0) lbase[t] = atomicAdd(cnt + lid[t], lcnt[t]);
+        if (lid[t] >= 0) {
+            const int m = hid[lid[t]];
+            lm[t] = m;
+            lbase[t] = atomicAdd(cnt + m, lcnt[t]);
+        }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
-        if (slot[j] >= 0) rank[e0 + 256 * j] = lbase[slot[j]] + lr[j];
+        if (slot[j] >= 0) {
+            off[e0 + 256 * j] = lm[slot[j]];                       // the entries hold dense point ids from here on
+            rank[e0 + 256 * j] = lbase[slot[j]] + lr[j];
+        }
 }
 __global__ __launch_bounds__(256) void crf_alloc_kernel(const int* __restrict__ cnt, int* __restrict__ start, const int* __restrict__ M,
                                                         int* __restrict__ cursor) {
