@@ -996,7 +996,11 @@ def main():
                    "vit_s_288_fp32_crf": guarded("seg vit-s crf", seg_eval_bench, dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
                    # BASELINE configs[1]: ViT-S, reference-faithful 288^2 input (324 patches), 21 VOC classes
                    "vit_s_288_fp32": guarded("seg vit-s fp32", seg_eval_bench, dev, world, "fp32", windows=64, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
-                   "vit_s_288_bf16": guarded("seg vit-s bf16", seg_eval_bench, dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
+                   "vit_s_288_bf16": guarded("seg vit-s bf16", seg_eval_bench, dev, world, "bf16", windows=256, img=288, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
+                   # BASELINE configs[1] at its stated size: ViT-S on PASCAL-VOC-shaped 512 x 512 inputs (1024 patches, interpolated position embedding), 21 classes
+                   "vit_s_512_fp32_crf": guarded("seg vit-s 512 crf", seg_eval_bench, dev, world, "fp32", windows=63, img=512, classes=21, tag="vit_small_patch16_224_in21k", dim=384, crf=True, steps=1),
+                   "vit_s_512_fp32": guarded("seg vit-s 512 fp32", seg_eval_bench, dev, world, "fp32", windows=63, img=512, classes=21, tag="vit_small_patch16_224_in21k", dim=384),
+                   "vit_s_512_bf16": guarded("seg vit-s 512 bf16", seg_eval_bench, dev, world, "bf16", windows=256, img=512, classes=21, tag="vit_small_patch16_224_in21k", dim=384)}
         # BASELINE configs[3] proper: 512 x 1024 source images through 3 overlapping windows each, stitched maps, images/s = SOURCE images
         seg["slide_512x1024"] = {"bf16": guarded("slide bf16", seg_slide_bench, dev, world, "bf16", images=256, steps=1, crf=False, window_batch=256),
                                  "bf16_crf": guarded("slide bf16 crf", seg_slide_bench, dev, world, "bf16", images=256, steps=1, crf=True, window_batch=256),
