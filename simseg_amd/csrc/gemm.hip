@@ -1928,7 +1928,15 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     }
     // (measured, tools/gemm_mid_bench.py: the ping-pong kernel is ahead of the 128x128 one from ~96 of its tiles on - e.g. the packed text
     //  tower's ~22 k x 768 problems, 255 tiles: 34 vs 52 us at K = 768, 98 vs 151 us at K = 3072)
-    if (v == 0) v = (big_ok && !TA && kper >= 12 && tiles256 >= 96) ? 3 : 1;
+    // Round 5 (tools/gemm_vits_bench.py, the ViT-S forward shapes at M = 262400): a SHORT contraction (K = 384: six slabs) is still 22-26 %
+    // faster on the ping-pong kernel once the problem is many rounds of tiles (qkv 502 -> 373 us, fc1 671 -> 521 us); and a column count that
+    // leaves the last 256-wide tile mostly empty (N = 384: a third of the matrix work wasted) is better off on the 128x128 kernel whatever K
+    // is (fc2: 653 -> 543 us).
+    if (v == 0) {
+        const int pad_n = ((p.N + 255) / 256) * 256 - p.N;
+        const bool n_fits = pad_n * 6 <= p.N;                              // <= 1/6 of the columns are padding
+        v = (big_ok && !TA && tiles256 >= 96 && n_fits && (kper >= 12 || (kper >= 6 && tiles256 >= 1024))) ? 3 : 1;
+    }
     if (v >= 10 && v <= 13 && !(big_ok && !TA)) v = 1;
     // one round of 128x128 tiles (more than the small-problem kernel takes, at most a block per CU): the ring variant's three slabs in
     // flight beat the register-staged kernel's one (14.7 vs 16.8 us on 1025 x 2304 x 768)
