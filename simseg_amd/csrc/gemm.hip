@@ -1930,11 +1930,12 @@ int dispatch_bf16(const GemmParams& p, int splitk, bool aligned, hipStream_t s) 
     //  tower's ~22 k x 768 problems, 255 tiles: 34 vs 52 us at K = 768, 98 vs 151 us at K = 3072)
     // Round 5 (tools/gemm_vits_bench.py, the ViT-S forward shapes at M = 262400): a SHORT contraction (K = 384: six slabs) is still 22-26 %
     // faster on the ping-pong kernel once the problem is many rounds of tiles (qkv 502 -> 373 us, fc1 671 -> 521 us); and a column count that
-    // leaves the last 256-wide tile mostly empty (N = 384: a third of the matrix work wasted) is better off on the 128x128 kernel whatever K
-    // is (fc2: 653 -> 543 us).
+    // leaves the last 256-wide tile mostly empty (N = 384: a third of the matrix work wasted) is better off on the 128x128 kernel up to K ~ 2500
+    // (fc2 at K = 1536: 653 -> 543 us; from K = 3072 on the long K loop wins again: 223 vs 177 us at M = 64575).
     if (v == 0) {
         const int pad_n = ((p.N + 255) / 256) * 256 - p.N;
-        const bool n_fits = pad_n * 6 <= p.N;                              // <= 1/6 of the columns are padding
+        const bool n_fits = pad_n * 6 <= p.N || kper >= 40;               // <= 1/6 of the columns are padding - or a contraction long enough
+                                                                            // (K >= 2560: the split-bf16 form of an fp32 product) to make up for it
         v = (big_ok && !TA && tiles256 >= 96 && n_fits && (kper >= 12 || (kper >= 6 && tiles256 >= 1024))) ? 3 : 1;
     }
     if (v >= 10 && v <= 13 && !(big_ok && !TA)) v = 1;
