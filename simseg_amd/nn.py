@@ -24,7 +24,7 @@ BERT_ARCH = {
 
 def compute_dtype():
     """The 16-bit type torch.autocast is set to (the reference trains under autocast, clip_runner.py:226-228: fp16 there, with a
-    GradScaler; bf16 is this package's headline mode) or the one SIMSEG_AMD_COMPUTE names (bf16 / fp16); exact fp32 otherwise (the
+    GradScaler - the benchmark headline since round 5; bf16 is the default 16-bit type of this package's own trainer) or the one SIMSEG_AMD_COMPUTE names (bf16 / fp16); exact fp32 otherwise (the
     eval tools run fp32)."""
     env = os.environ.get("SIMSEG_AMD_COMPUTE", "").lower()
     if env in ("bf16", "bfloat16"):

@@ -32,7 +32,7 @@ class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-3, half_dtype=torch.bfloat16):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if half_dtype not in (torch.bfloat16, torch.float16):
-            raise TypeError("half_dtype: torch.bfloat16 (headline mode) or torch.float16 (the reference's AMP type)")
+            raise TypeError("half_dtype: torch.bfloat16 (the default) or torch.float16 (the reference's AMP type, the benchmark headline since round 5)")
         self.half_dtype = half_dtype      # type of the 16-bit compute copies the kernel writes (what the towers' GEMMs read next step)
         self._step = 0                    # step() calls without a GradScaler (every one of them updates)
         self._step_dev = None             # AMP: float32 [2] on the device, the count of steps actually TAKEN (skipped ones do not count)
