@@ -43,7 +43,9 @@ def crf_masks(prob, cand_idx, images_u8, chunk=None, scale=1, static=None, **par
         m, _ = ops.dense_crf(images_u8.contiguous(), up.contiguous(), **dict(CRF_PARAMS, **params))
         return m * (cand_idx >= 0).to(torch.uint8)[:, :, None, None]
     if chunk is None:
-        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "32"))      # (16 -> 32: 25.5 -> 24.7 ms per 63-window batch of 512^2, 9.9 -> 9.1 ms at 288^2; 64 no better)
+        # images per call: ~16.7 M pixels (64 windows of 512^2, 32 images of 512 x 1024; 17.7 GB of workspace).  Round 5, after the lattice
+        # build became cheaper per image: 16 / 32 / 64 windows of 512^2 per call = 20.7 / 19.9 / 19.1 ms per 63-window batch
+        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "0")) or max(8, min(128, (1 << 24) // (H * W)))
     masks = torch.zeros(B, K, H, W, device=dev, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
