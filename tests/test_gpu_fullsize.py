@@ -311,3 +311,45 @@ def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
               f"max {max(base.values()):.4e} / {max(d.values()):.4e}")
         assert not worse, worse[:5]
         assert np.mean(list(d.values())) <= 1.05 * np.mean(list(base.values())) + 1e-5
+
+
+def test_sliding_window_full_config4_properties(monkeypatch):
+    """BASELINE configs[3] at its full size - ViT-B/16, 512 x 1024 source images, 3 windows of 512^2 at stride 256, 171 classes - through
+    size-independent properties of the stitch (the oracle loop is far too slow here; tests/test_gpu_miou_gate.py pins the pipeline
+    against it at a small size):  the stitched map equals window 0 / window 2 where only they cover the image (patch columns 0-15 /
+    48-63), is the mean of the two covering windows in between, the image scores are the mean of the window scores, and the areas the
+    evaluation accumulates are exactly the labelled pixels.  Exact fp32 and bf16."""
+    from simseg_amd import ops, segpost
+    from simseg_amd.heads import patch_text_similarity
+    B, H, W, C, win, stride = 2, 512, 1024, 171, 512, 256
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 3, H, W, generator=g).cuda()
+    text = F.normalize(torch.randn(C, 512, generator=g), dim=-1).cuda()
+    labels = torch.randint(0, C, (B, H, W), generator=g, dtype=torch.int64).to(torch.uint8)
+    labels[torch.rand(B, H, W, generator=g) < 0.05] = 255
+    labels = labels.cuda()
+    torch.manual_seed(5)
+    model = _build_vitb(win).cuda().eval()
+    for mode, sim_dt, tol in (("fp32", None, 0.0), ("bf16", torch.bfloat16, 0.0)):
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+        with torch.no_grad():
+            wins = segpost.extract_windows(x, win, stride)
+            assert wins.shape == (B * 3, 3, win, win) and torch.equal(wins[4], x[1, :, :, 256:768])
+            feats = model.forward_image_feature(wins)
+            sim_w = patch_text_similarity(model.image_projection(feats), text, compute_dtype=sim_dt).float()      # [6, 1024, C]
+            sc_w = ops.gemm(model.forward_image_project(feats).float(), text)
+            st = segpost.encode_batch_sliding(model, x, text, 10, win=win, stride=stride, crf=False, sim_dtype=sim_dt)
+            sim = ops.stitch_windows(sim_w, 1, 3, 32, 16).view(B, 32, 64, C)
+        w = sim_w.view(B, 3, 32, 32, C)
+        assert torch.equal(sim[:, :, :16], w[:, 0, :, :16]) and torch.equal(sim[:, :, 48:], w[:, 2, :, 16:])
+        assert torch.equal(sim[:, :, 16:32], (w[:, 0, :, 16:] + w[:, 1, :, :16]) / 2) and torch.equal(sim[:, :, 32:48], (w[:, 1, :, 16:] + w[:, 2, :, :16]) / 2)
+        sc = ((sc_w.view(B, 3, C)[:, 0] + sc_w.view(B, 3, C)[:, 1]) + sc_w.view(B, 3, C)[:, 2]) / 3
+        ci, cs, _ = ops.seg_select(sc, 10)
+        # (the pipeline's own pass over the towers is a second launch sequence: scores agree to rounding, candidates exactly)
+        assert torch.equal(ci, st["cand_idx"]) and torch.allclose(cs, st["cand_score"], rtol=1e-5 if mode == "fp32" else 2e-2, atol=1e-6)
+        assert st["masks"].shape == (B, 5, H, W)
+        hist = torch.zeros(3, C, device="cuda", dtype=torch.int64)
+        with torch.no_grad():
+            out = segpost.finish_batch(st, labels, hist=hist, want_pred=True)
+        assert int(hist[2].sum()) == int((labels != 255).sum()) == int(hist[1].sum())
+        assert int(hist[0].sum()) == int(((out["pred"] == labels.int()) & (labels != 255)).sum())
