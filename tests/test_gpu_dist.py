@@ -454,3 +454,77 @@ def test_sharded_seg_evaluation_two_ranks_equals_single_process():
     assert torch.equal(got[0]["hist"], got[1]["hist"]) and torch.equal(got[0]["hist"], got[0]["want"])
     assert int(got[0]["hist"][2].sum()) <= 8 * 96 * 192 and int(got[0]["hist"][1].sum()) > 0
     assert torch.equal(got[0]["plain_hist"], got[0]["want_plain"]) and got[0]["plain_images"] == 8
+
+
+def _worker_amp_sync(rank, world, port, backend, q):
+    """The bench's N > 1 headline step in small: fp16 compute, loss scaled by a live GradScaler, GradSync bucket exchange with the mean left to
+    the optimizer kernel, overflow check on the exchanged gradients, fused AdamW - two steps, then one with an inf forced on ONE rank."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if torch.cuda.device_count() >= world else 0), SIMSEG_AMD_COMPUTE="fp16", SIMSEG_AMD_TWO_STREAMS="1")
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from simseg.utils import ENV
+        ENV.rank, ENV.size, ENV.local_rank = rank, world, dev.index
+        from simseg_amd.optim import AdamW, GradScaler
+        from simseg_amd.parallel import GradSync
+        from test_gpu_model import _build
+        g = np.load(os.path.join(GOLD, f"clip_train_ws{world}.npz"))
+
+        def golden(name):
+            return np.load(os.path.join(GOLD, name + ".npz"))
+
+        batch = {k: torch.from_numpy(g[f"r{rank}.{k}"]).to(dev) for k in ("image", "input_ids", "attention_mask")}
+        model = _build(golden).eval()                    # (eval: BERT dropout off - the ranks' functions differ by their data only)
+        p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+        sync = GradSync(model.parameters(), overlap=True, average="defer")
+        opt = AdamW(model.parameters(), lr=1e-3, half_dtype=torch.float16)
+        scaler = GradScaler("cuda", init_scale=1024.0)
+        losses = []
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = model(batch)[0]["nce_loss"]
+            # step 2: an overflow on ONE rank (its loss blown up before the scaled backward: fp16 gradients saturate) - the exchanged
+            # gradient is then non-finite on EVERY rank
+            scaler.scale(loss * (1e8 if (step == 2 and rank == 1) else 1.0)).backward()
+            sync()
+            scaler.step(opt, grad_scale=sync.grad_scale)
+            scaler.update()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        taken = opt.steps_taken()
+        moved = max(float((p.detach() - p0[n]).abs().max()) for n, p in model.named_parameters())
+        flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        q.put((rank, {"losses": losses, "taken": taken, "scale": scaler.get_scale(), "moved": moved, "finite": bool(torch.isfinite(flat).all()),
+                      "same_as_rank0": bool(torch.equal(flat, ref))}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_fp16_amp_step_with_gradsync():
+    """Two ranks run the N > 1 form of the benchmark's headline step (fp16 + GradScaler + GradSync + fused AdamW): both take the same two
+    updates and stay bit-identical, the step with an inf injected on rank 1 only is skipped on BOTH ranks (the overflow check reads the
+    exchanged gradients) and halves the loss scale on both."""
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_amp_sync, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    for r in range(world):
+        assert got[r]["taken"] == 2 and got[r]["scale"] == 512.0 and got[r]["finite"] and got[r]["moved"] > 0, got[r]
+        assert got[r]["same_as_rank0"], "the ranks' parameters diverged"
+        assert all(np.isfinite(got[r]["losses"]))
