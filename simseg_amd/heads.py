@@ -11,6 +11,12 @@ from . import ops
 F32 = torch.float32
 
 
+def _one(world):
+    """The one-rank shortcut applies (see parallel.force_collectives: SIMSEG_FORCE_COLLECTIVES=1 keeps the collectives at world size 1)."""
+    from .parallel import force_collectives
+    return world == 1 and not force_collectives()
+
+
 # Embedding all-gathers started ahead of their use (prefetch_gather): id(tensor) -> (weakref, input, output, work).  The exchange
 # of one tower's [Bl, P] embeddings then runs on the collective's own stream underneath the OTHER tower's kernels.
 _PREFETCH = {}
@@ -26,7 +32,7 @@ def prefetch_gather(tensor, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if _one(world):
         return
     t = tensor.detach().contiguous()
     out = torch.empty(_gathered_shape(t, world), device=t.device, dtype=t.dtype)
@@ -79,7 +85,7 @@ class GatherLayer(Function):
             return out
         tensor = tensor.contiguous()
         out = torch.empty(_gathered_shape(tensor, world), device=tensor.device, dtype=tensor.dtype)
-        if world == 1:
+        if _one(world):
             out.copy_(tensor)
         else:
             dist.all_gather_into_tensor(out, tensor, group=group)
@@ -89,7 +95,7 @@ class GatherLayer(Function):
     def backward(ctx, grad):
         world = dist.get_world_size(ctx.group)
         grad = grad.contiguous()
-        if world == 1:
+        if _one(world):
             return grad.clone(), None, None
         own = torch.empty((ctx.bl,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
         dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=ctx.group)
@@ -103,7 +109,7 @@ def all_gather_rows(tensor, group):
     if out is not None:
         return out
     tensor = tensor.detach().contiguous()
-    if world == 1:
+    if _one(world):
         return tensor
     out = torch.empty(_gathered_shape(tensor, world), device=tensor.device, dtype=tensor.dtype)
     dist.all_gather_into_tensor(out, tensor, group=group)
@@ -160,7 +166,8 @@ class ClipLossFn(Function):
     def forward(ctx, img, txt, temperature, group, rank, smoothing, gather_backward):
         img32, txt32 = img.contiguous().float(), txt.contiguous().float()
         world = dist.get_world_size(group) if group is not None else 1
-        if world > 1:
+        multi = group is not None and not _one(world)          # the exchange runs: several ranks, or a one-rank group with SIMSEG_FORCE_COLLECTIVES=1
+        if multi:
             img_g = _take_prefetched(img, group)
             txt_g = _take_prefetched(txt, group)
             if img_g is None:
@@ -178,8 +185,8 @@ class ClipLossFn(Function):
         ops.gemm(txt32, img_g, out=sims[1])
         need = any(ctx.needs_input_grad[:3])
         out4 = ops.nce_pair(sims, temperature.detach().reshape(1).float(), rank * Bl, smoothing, write_grad=need)
-        ctx.group, ctx.world, ctx.rank, ctx.gb = group, world, rank, gather_backward
-        ctx.save_for_backward(sims if need else None, img32, txt32, img_g if world > 1 else None, txt_g if world > 1 else None, out4)
+        ctx.group, ctx.world, ctx.rank, ctx.gb, ctx.multi = group, world, rank, gather_backward, multi
+        ctx.save_for_backward(sims if need else None, img32, txt32, img_g if multi else None, txt_g if multi else None, out4)
         loss, a1, a2 = out4[0].clone(), out4[1].clone(), out4[2].clone()
         ctx.mark_non_differentiable(a1, a2)
         return loss, a1, a2
@@ -187,12 +194,12 @@ class ClipLossFn(Function):
     @staticmethod
     def backward(ctx, gloss, _g1, _g2):
         ds, img32, txt32, img_g, txt_g, out4 = ctx.saved_tensors
-        world = ctx.world
+        one = not ctx.multi                                     # no exchange: the "gathered" embeddings are the local ones
         g = gloss.contiguous().float().reshape(1)
         need_img, need_txt, need_t = ctx.needs_input_grad[:3]
         x0 = out4[3:4] if need_t else None
         # ONE launch: both gradient blocks times 0.5 * g (in place and transposed) + the transposed embeddings; dT * g on the way
-        if world == 1:
+        if one:
             (dsi_t, dst_t, txt_t, img_t), dt = ops.transpose_multi([ds[0], ds[1], txt32, img32], [1, 1, 0, 0], scalar=g, alpha=0.5, x0=x0)
             txtg_t, imgg_t = txt_t, img_t
         else:
@@ -206,7 +213,7 @@ class ClipLossFn(Function):
         if need_img:
             dimg = ops.gemm(ds[0], txtg_t)                                   # dS_i . txt_g          [Bl, P]
             if through_gather:
-                if world == 1:
+                if one:
                     ops.gemm(dst_t, txt_t, out=dimg, accumulate=True)        # + dS_t^T . txt
                 else:
                     dimg_g = ops.gemm(dst_t, txt_t)                          # [Bg, P]: every rank's rows; this rank keeps the sum of its own
@@ -216,7 +223,7 @@ class ClipLossFn(Function):
         if need_txt:
             dtxt = ops.gemm(ds[1], imgg_t)                                   # dS_t . img_g
             if through_gather:
-                if world == 1:
+                if one:
                     ops.gemm(dsi_t, img_t, out=dtxt, accumulate=True)        # + dS_i^T . img
                 else:
                     dtxt_g = ops.gemm(dsi_t, img_t)

@@ -32,6 +32,14 @@ import torch.distributed as dist
 _EVENTS = os.environ.get("SIMSEG_GRADSYNC_EVENTS", "needed")      # "all": an event per parameter, as before round 4 (A/B runs)
 
 
+def force_collectives():
+    """SIMSEG_FORCE_COLLECTIVES=1: a process group of ONE rank still issues every collective of the data path (all-reduce of the gradient
+    buckets, the int64 MIN / MAX check of the bucket cut; heads.py: embedding all-gather / reduce-scatter) instead of taking the one-rank
+    shortcuts.  The arithmetic is the same; what it buys is running the N > 1 code path - communication stream, events, Work handles,
+    record_stream hand-overs - on real RCCL on a box with a single GPU (RCCL refuses two ranks per device, but serves a one-rank group)."""
+    return os.environ.get("SIMSEG_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 class GradSync:
     def __init__(self, params, group=None, average=True, overlap=True, bucket_mb=64):
         self.params = [p for p in params if p.requires_grad]
@@ -137,7 +145,7 @@ class GradSync:
                     run["st"] = st
                 run["members"].append(i); run["n"] += self.params[i].numel()
                 lo += self.params[i].numel()
-        if self._world() > 1:       # every rank must cut the same way (the collectives are per bucket): same code, same streams - checked once
+        if self._world() > 1 or force_collectives():       # every rank must cut the same way (the collectives are per bucket): same code, same streams - checked once
             sig = torch.tensor([len(out), sum((k + 1) * r["lo"] for k, r in enumerate(out)) % (1 << 40)], device=self.flat.device, dtype=torch.int64)
             lo_, hi_ = sig.clone(), sig.clone()
             dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=self.group)
@@ -240,7 +248,7 @@ class GradSync:
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._gather_bucket(b)
-                if self._world() > 1:
+                if self._world() > 1 or force_collectives():
                     self._reduce(b)
         return hook
 
@@ -258,13 +266,13 @@ class GradSync:
             self._copied += len(dst)
             if dst:
                 torch._foreach_copy_(dst, src)
-            if world > 1:
+            if world > 1 or force_collectives():
                 dist.all_reduce(self.flat, group=self.group)
         else:
             for b, left in enumerate(self._pending):
                 if left:                           # a bucket with parameters that got no gradient this step (they count as zero)
                     self._gather_bucket(b)
-                    if world > 1:
+                    if world > 1 or force_collectives():
                         self._reduce(b)
             for w in self._works:
                 w.wait()                           # the current stream waits for the collective (RCCL: no host block)

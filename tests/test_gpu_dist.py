@@ -528,3 +528,86 @@ def test_two_ranks_fp16_amp_step_with_gradsync():
         assert got[r]["taken"] == 2 and got[r]["scale"] == 512.0 and got[r]["finite"] and got[r]["moved"] > 0, got[r]
         assert got[r]["same_as_rank0"], "the ranks' parameters diverged"
         assert all(np.isfinite(got[r]["losses"]))
+
+
+def _worker_rccl_one_rank(port, q):
+    """ONE rank on the `nccl` backend (= RCCL; it refuses two ranks per device but serves a one-rank group): the training step with every
+    collective of the N > 1 data path issued (SIMSEG_FORCE_COLLECTIVES=1) against the same step with the one-rank shortcuts."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SIMSEG_AMD_COMPUTE="fp16",
+                      SIMSEG_AMD_TWO_STREAMS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from simseg.utils import ENV
+        ENV.rank, ENV.size, ENV.local_rank = 0, 1, 0
+        from simseg_amd.optim import AdamW, GradScaler
+        from simseg_amd.parallel import GradSync
+        from test_gpu_model import _build
+        g = np.load(os.path.join(GOLD, "clip_train_ws2.npz"))
+
+        def golden(name):
+            return np.load(os.path.join(GOLD, name + ".npz"))
+
+        batch = {k: torch.from_numpy(g[f"r0.{k}"]).cuda() for k in ("image", "input_ids", "attention_mask")}
+        calls = {}
+        for name in ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor"):
+            real = getattr(dist, name)
+
+            def counted(*a, _real=real, _name=name, **kw):
+                calls[_name] = calls.get(_name, 0) + 1
+                return _real(*a, **kw)
+            setattr(dist, name, counted)
+        out = {}
+        for force in ("0", "1"):
+            os.environ["SIMSEG_FORCE_COLLECTIVES"] = force
+            calls.clear()
+            model = _build(golden).eval()
+            assert model.loss.group is not None and dist.get_backend(model.loss.group) == "nccl"
+            sync = GradSync(model.parameters(), overlap=True, average="defer")
+            opt = AdamW(model.parameters(), lr=1e-3, half_dtype=torch.float16)
+            scaler = GradScaler("cuda", init_scale=1024.0)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = model(batch)[0]["nce_loss"]
+                scaler.scale(loss).backward()
+                sync()
+                scaler.step(opt, grad_scale=sync.grad_scale)
+                scaler.update()
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            out[force] = {"losses": losses, "taken": opt.steps_taken(), "calls": dict(calls), "buckets": len(sync.buckets),
+                          "params": torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()}
+            sync.close()
+        q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_runs_every_collective_of_the_step():
+    """Real RCCL on the one-GPU box: with SIMSEG_FORCE_COLLECTIVES=1 a one-rank `nccl` group issues the embedding all-gathers (prefetched on
+    the towers' streams, handed over with record_stream), the reduce-scatters of their gradients, the bucketed gradient all-reduces on the
+    communication stream behind the producers' events and the int64 MIN / MAX check of the bucket cut - the code the N > 1 benchmark runs -
+    and the fp16 AMP step gives the losses and parameters of the same step with the one-rank shortcuts."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(60)
+    plain, forced = out["0"], out["1"]
+    assert plain["calls"].get("all_gather_into_tensor", 0) == 0 and plain["calls"].get("reduce_scatter_tensor", 0) == 0
+    c = forced["calls"]
+    assert c.get("all_gather_into_tensor", 0) >= 6 and c.get("reduce_scatter_tensor", 0) >= 6, c          # 2 per step: image and text embeddings
+    # every bucket of every step: the first step's single 64-MiB bucket + the int64 MIN / MAX check of the cut at the tower-stream
+    # boundaries + the stream-pure buckets of the two later steps
+    assert c.get("all_reduce", 0) >= 1 + 2 + 2 * forced["buckets"] and forced["buckets"] > 1, (c, forced["buckets"])
+    assert forced["taken"] == plain["taken"] == 3
+    np.testing.assert_allclose(forced["losses"], plain["losses"], rtol=2e-3)
+    rel = float((forced["params"] - plain["params"]).norm() / plain["params"].norm())
+    assert rel < 1e-4, rel
