@@ -34,6 +34,7 @@ def log(msg):
 
 
 TRAFFIC_JSON = "r5_pmc_traffic.json"
+_JSON_FD = 1        # where the one JSON line goes (main() parks the real stdout here and points fd 1 at stderr)
 
 
 def git_blob_sha1(path):
@@ -716,6 +717,13 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                             # does not return: this process becomes the launcher of N ranks
+    # stdout carries the ONE JSON line and nothing else: file descriptor 1 is parked and re-pointed at stderr for the whole run, so whatever a
+    # library writes to the C-level stdout (RCCL prints a version banner there, flushed at exit - i.e. AFTER the line - when stdout is a
+    # pipe) cannot land next to it; rank 0 writes the line to the parked descriptor at the end.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     HEAD = os.environ.get("SIMSEG_BENCH_HEADLINE", "fp16").lower()      # the headline step's arithmetic: the reference's own AMP type (fp16 +
     assert HEAD in ("fp16", "bf16"), HEAD                               #  a live GradScaler, clip_runner.py:226-230); "bf16": round 1-4's headline
     os.environ["SIMSEG_AMD_COMPUTE"] = HEAD
@@ -1101,7 +1109,8 @@ def main():
                        "process_group": pg_info, "batches_rotated": NB,
                        "caption_lengths": ("host-side token counts travel with the batch (no host read in the step)" if HOST_LENGTHS
                                            else "derived from the device mask (one host read per step)"),
-                       "gradient_sync": ((f"simseg_amd.parallel.GradSync ({dp})" + (" [forced on one rank: no collective]" if world == 1 else "")) if sync is not None
+                       "gradient_sync": ((f"simseg_amd.parallel.GradSync ({dp})" + ((" [forced on one rank: every collective issued on the one-rank " + str(pg_info["backend"]) + " group]" if os.environ.get("SIMSEG_FORCE_COLLECTIVES", "0") == "1"
+                                                                                        else " [forced on one rank: no collective]") if world == 1 else "")) if sync is not None
                                          else ("none" if world == 1 else "torch DDP")),
                        "gradient_sync_detail": ({"zero_copy_weight_gradients": ZERO_COPY, "gradients_copied_per_step": sync.copied_last,
                                                  "events_per_step": sync.events_last, "buckets": len(sync.buckets)} if sync is not None else None),
@@ -1154,7 +1163,8 @@ def main():
             "retrieval_eval": retr,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         if world > 1:
             dist.barrier()
