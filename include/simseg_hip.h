@@ -145,6 +145,11 @@ int simseg_debug_gemm_wgrad_blocks(int blocks);
  * leave the other rows of out / lse / dqkv untouched. */
 int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int dtype, int64_t B, int64_t T,
                          int64_t H, float scale, uint64_t drop_seed, float drop_p, int skip_padded_rows, void* stream);
+/* The same forward for long 16-bit sequences (T >= 512, no mask, no dropout: timm Attention.forward at img_size 384 / 512,
+ * vit_builder.py:18 via pipelines/clip.py:193-194) on a projection whose q columns already carry scale * log2(e): the caller folds the
+ * factor into the q rows of Attention.qkv's weight and bias BEFORE rounding them to 16 bits, so q * scale is rounded once - exactly as q
+ * alone would have been - and the kernel's exponent is the MFMA output itself (no multiply per score). */
+int simseg_attention_fwd_qscaled(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, void* stream);
 /* Backward: dqkv[B,T,3,H,64] from qkv, ctx, dctx and lse, all in `dtype` (0 = fp32: the exact mode of a non-AMP run,
  * simseg/core/hooks/optimizer.py:76-77; 1 = bf16).  workspace: caller-provided fp32 scratch of simseg_attention_bwd_workspace_bytes(B, T, H).
  * dqkv_colsum (optional, [3*H*64] fp32) += column sums of dqkv over all B*T rows: the bias gradient of the q/k/v projection (timm

@@ -35,6 +35,8 @@ struct AttnParams {
     long rs, ps;        // resident forward / one-kernel backward: element strides of qkv / dqkv - row r of plane (which * H + h), which = 0 q, 1 k, 2 v,
                         // starts at plane * ps + r * rs.  Packed projection rows [rows, 3, H, 64]: rs = 3 * H * 64, ps = 64; plane-major
                         // [3 * H][rows][64] (a head's operand rows are ONE contiguous run): rs = 64, ps = rows * 64
+    int qscaled;        // w64 forward: the q columns of qkv already carry scale * log2(e) (simseg_attention_fwd_qscaled)
+    int gxm, gxw;       // w64 forward: main blocks / all blocks per (batch, head)
     int pf_stride;      // one-kernel backward: > 0 = touch the operands of head blockIdx.x + pf_stride (the head that takes this CU's place in the
                         // next round) during the tile loop, so that its copies find them in this XCD's L2; 0 = off
 };
@@ -730,6 +732,539 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit forward, long sequences without mask / dropout (round 6: the ViT towers at 384^2 / 512^2, T = 577 / 1025): 64 QUERIES PER WAVE.
+// The ring kernel above gives a wave one 32-query block: every K / V fragment it reads from LDS (16 KB per 64-key tile and wave) feeds ONE
+// MFMA, and with three waves per SIMD the LDS pipe is as busy as the matrix pipe.  Here a wave owns TWO 32-query blocks (a, b): each K
+// fragment (MFMA A operand of S^T = K.Q^T) and each transposed V fragment (A operand of O^T = V^T.P^T) feeds two MFMAs, 32 MFMAs per tile and
+// wave against the same 24 LDS reads.  Four waves (256 queries) per block, two blocks per CU (256 registers per wave).
+//   * Key 0 (the class token) does not open a tile of its own: the online softmax STARTS from it - m = s_0, l = 1, O = v_0 (a rank-1 state
+//     formed from one dot product per query) - and the tiles cover keys 1 .. T-1: exactly 16 full tiles at T = 1025 instead of 16 + one
+//     tile holding a single key.  A remainder (T - 1) % 64 > 0 is the masked last tile.
+//   * A block's waves past the last query row keep issuing their share of the K / V copies and meet the barriers, nothing else.
+// Measured ratios behind the shape (tools/scratch/ubench_issue.hip, profiles/r6_ubench_issue.txt): one wave issues a plain VALU
+// instruction every 5.8-6.8 cycles and v_exp_f32 every 9.8; only ~5 of them hide under one 32-cycle MFMA of the same wave, and a D = 64
+// tile needs ~9 per MFMA - the softmax of one wave must run under the MFMAs of the SIMD's other wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int W64_MINT = 512;          // (shorter sequences - 325 tokens at 288^2 - fill two 256-row blocks badly and stay on the ring kernel)
+// A half-row's probability sum over a key block above this (or not finite) re-centres the row.  P and the sums have the relative precision
+// of their formats at any magnitude, so the bound only has to keep P representable: 2^14 for fp16 (largest finite 65504), 2^30 for bf16.
+// (At 2^8 peaked rows - a few keys far above the class token's score, the first offset - sent a wave through the re-centring path every
+// few tiles: unscaled N(0,1) operands, scores of +-30 in the exponent, ran 20 % slower than scaled ones.)
+#ifdef SS_HALF
+constexpr float W64_BIG = 16384.0f;
+#else
+constexpr float W64_BIG = 1073741824.0f;
+#endif
+
+// The w64 kernel's K / V copies: buffer loads straight into LDS.  One descriptor per (batch, head) whose range ends with the batch's last
+// row - rows past T read as zeros, no per-row clamp - a lane's share of the address is two 32-bit offsets fixed for the whole kernel (its row
+// within an 8-row piece, its swizzled chunk, the K / V plane), the tile and the piece are a scalar offset: no 64-bit address arithmetic and
+// no pointer registers in the tile loop (the ring kernel spends ~10 VALU instructions per piece on them).  Wave w copies pieces w and w + 4
+// of K and of V (8 rows of 128 B each).
+__device__ __forceinline__ void w64_dma(__amdgpu_buffer_rsrc_t rsrc, int offK, int offV, int row0, int rs_bytes, char* stage, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p8 = wave + 4 * i;
+        const int so = (row0 + p8 * 8) * rs_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + p8 * 1024), 16, offK, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + KT * 128 + p8 * 1024), 16, offV, so, 0, 0);
+    }
+}
+
+// The softmax of one 32-key block of the w64 kernel, all of the wave's query blocks, in 4 * NQB steps of four scores (one step per MFMA of
+// the phase it shares with the other key block's matrix work).  d[qb][r] IS the exponent: the score chains start from the tuple `negm`
+// (= -m in all 16 registers: the MFMA's C operand) and the queries carry scale * log2(e), so P = exp2(d) with no multiply, subtract or
+// maximum on the way - one v_exp, one add and half a convert per score, each exponent register dead after its v_exp.  The running offset m
+// only has to keep P in range (any per-row offset cancels in O / l).  acc: four partial half-row sums per query block; the caller tests
+// their total.  pk[qb][s2]: P as the PV products' B operands, the eight keys of 16-key step s2.
+// QS = false (the generic entry point: q as the projection delivers it): d is the RAW score minus the offset, in raw units, and the scale
+// c = scale * log2(e) goes into one multiply per score in front of the v_exp - no second rounding of q.
+template <int NQB, bool QS>
+__device__ __forceinline__ void softmax_w64_step(int i, const f32x16 (&d)[NQB], bf16x8 (&pk)[NQB][2], float (&acc)[NQB][4], float c) {
+    constexpr int RS = 4 / NQB;                  // scores per query block and step
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            const int r = i * RS + j;
+            const float pr = __builtin_amdgcn_exp2f(QS ? d[qb][r] : d[qb][r] * c);
+            acc[qb][r & 3] += pr;
+            pk[qb][r >> 3][r & 7] = (bf16_t)pr;
+        }
+    }
+    // (the sums and the packed pairs are pinned to THIS step: left alone the compiler pairs the adds of both query blocks into v_pk_add_f32
+    //  and sinks all of them, and the converts, behind the phase's last MFMA - ~50 instructions that nothing covers)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        union { bf16x8 v; unsigned w[4]; } u;
+        const int r0 = i * RS;
+        u.v = pk[qb][r0 >> 3];
+        if (RS == 2) asm volatile("" : "+v"(acc[qb][r0 & 3]), "+v"(acc[qb][(r0 + 1) & 3]), "+v"(u.w[(r0 & 7) >> 1]));
+        else asm volatile("" : "+v"(acc[qb][0]), "+v"(acc[qb][1]), "+v"(acc[qb][2]), "+v"(acc[qb][3]), "+v"(u.w[(r0 & 7) >> 1]), "+v"(u.w[((r0 & 7) >> 1) + 1]));
+        pk[qb][r0 >> 3] = u.v;
+    }
+}
+
+// The rare path for one query block: some half-row's sum over a key block left [0, W64_BIG] (or is not finite) - never while m is the row's
+// true maximum, since the sum of 16 probabilities is then at most 16.  d: the block's exponents, formed AGAIN by the caller (the fast path
+// lets them die).  Raises m by max(0, largest exponent) per row (rows in range keep theirs), rescales O and l, rewrites the offset tuple
+// and P; returns the new half-row sum and, in `inc`, what the caller still has to subtract from exponents formed with the old offset.
+// (m, d, inc in the exponent's own units - raw score units with c = scale * log2(e) when q is not pre-scaled, else c = 1)
+__device__ __forceinline__ float w64_recenter(const f32x16& d, bf16x8 (&pk)[2], float& m, f32x16& negm, float& lsum, f32x16 (&o)[2], float& inc,
+                                              float c) {
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx[r & 3] = fmaxf(mx[r & 3], d[r]);
+    inc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    inc = fmaxf(inc, __shfl_xor(inc, 32, 64));
+    const float alpha = __builtin_amdgcn_exp2f(-inc * c);
+    m += inc;
+    lsum *= alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -m;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f((d[r] - inc) * c);
+        acc[r & 3] += pr;
+        pk[r >> 3][r & 7] = (bf16_t)pr;
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// NQB: 32-query blocks per wave - 2 = the form described above (256 registers, two waves per SIMD); 1 = the same schedule with one block
+// per wave (four waves = 128 queries per block, 168 registers, three waves per SIMD: every fragment feeds one MFMA again, but a third wave
+// issues beside the two - one wave issues a VALU instruction every 6-10 cycles whatever its neighbours do).
+// HAS_EDGE: (T - 1) % 64 != 0 - the instantiation that carries the masked last tile (a second copy of the tile body: spilled registers;
+// the towers' long sequences - 577, 1025, 2305 tokens - do not need it)
+// SPLIT: the launch for the rows behind a (batch, head)'s last full block (T = 1025: ONE row).  A block then holds two row groups with TWO
+// waves each: the second wave takes the tiles' second 32-key block (the first wave their first), each with the plain sequence scores ->
+// softmax -> PV on its half, and the two partial softmax states (m, l, O) are merged through LDS at the end.  (One barrier per tile ties a
+// block's waves to the same tile, so keys can only be split inside a tile.)  Run with one query block per wave at three blocks per CU: as
+// part of the main launch the underfilled fifth block of every (batch, head) - one wave with one valid row holding a two-per-CU block slot
+// for a full pass over the keys - took 21 % of the kernel's block-slot time at T = 1025.
+// One block's work: (batch, head) bh_, block qblk of the rows from qbase on.  gx: blocks per (batch, head) of the launch (DBG records only).
+template <int NQB, bool SPLIT, bool HAS_EDGE, bool QS, bool DBG>
+__device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh_, int qblk, int qbase, int gx) {
+    constexpr int RW = 32 * NQB, RB = (SPLIT ? 2 : 4) * RW;       // query rows per wave / per block
+    constexpr int NS = 4 * NQB;                     // MFMAs per phase
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h2 = lane >> 5, ql = lane & 31;
+    const int T = p.T;
+    const int b = bh_ / p.H, h = bh_ % p.H;
+    const long RS = 3L * p.H * 64;
+    const int HD = p.H * 64;
+    const bf16_t* base = static_cast<const bf16_t*>(p.qkv) + (long)b * T * RS + h * 64;
+    const int grp = SPLIT ? (wave & 1) : wave, part = SPLIT ? (wave >> 1) : 0;
+    const int q0 = qbase + qblk * RB + grp * RW;
+    const bool active = q0 < T;                     // wave-uniform
+    const int rem = (T - 1) & 63;                   // keys of the last, partial tile (tiles start at key 1)
+    const int nt = ((T - 1) >> 6) + (rem ? 1 : 0);
+    constexpr int per = 4;
+    unsigned long long dbg[7] = {0, 0, 0, 0, 0, 0, 0}, dt0 = 0;      // DBG: {prologue, copies issued, phases 1 + 2, phase 3, phase 4, tile wait, barrier} cycle sums
+    const unsigned long long dbg_start = DBG ? __builtin_readcyclecounter() : 0;
+    auto stamp = [&](int slot, float touch) {
+        if constexpr (DBG) {
+            float t_;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"(touch));
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            dbg[slot] += t1 - dt0;
+            dt0 = t1;
+        }
+    };
+    if (DBG) dt0 = dbg_start;
+
+    // tiles 0 and 1 on their way first; Q, k_0, v_0 behind them
+    const int rs_bytes = (int)RS * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, T * rs_bytes - h * 128, 0x00020000);
+    const int drow = lane >> 3;                     // row within an 8-row piece; k_swz / v_swz of the row depend on the lane only
+    const int offK = drow * rs_bytes + HD * 2 + (((lane & 7) ^ ((lane >> 4) & 3) ^ ((wave & 1) << 2)) << 4);
+    const int offV = drow * rs_bytes + HD * 4 + (((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4);
+    if (nt > 0) w64_dma(rsrc, offK, offV, 1, rs_bytes, lds, wave);
+    if (nt > 1) w64_dma(rsrc, offK, offV, 1 + KT, rs_bytes, lds + GSTAGE, wave);
+    bf16x8 qr[NQB][4];                              // QS: the projection's q columns carry scale * log2(e) (simseg_attention_fwd_qscaled)
+    const float cexp = QS ? 1.0f : p.scale_log2e;   // what an exponent is multiplied by in front of the v_exp
+    f32x16 o[NQB][2];                               // [query block][d block], unnormalised
+    f32x16 negm[NQB];
+    float m[NQB], lsum[NQB];
+    {
+        bf16x8 k0[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) k0[kk] = ld_bf16x8(base + HD + (2 * kk + h2) * 8);
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            int q = q0 + qb * 32 + ql;
+            q = q < T ? q : T - 1;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) qr[qb][kk] = ld_bf16x8(base + (long)q * RS + (2 * kk + h2) * 8);
+        }
+        bf16x4 v0[2][4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) v0[db][r4] = *reinterpret_cast<const bf16x4*>(base + 2 * HD + db * 32 + 8 * r4 + 4 * h2);
+        // key 0 opens the softmax: m = s_0, p_0 = 1, l = 1, O = v_0.  The offset tuple -s_0 comes out of the matrix pipe: an A fragment whose 32
+        // rows all hold -k_0 gives every register of the result this lane's -q.k_0 (the dot product in VALU instructions took ~300 of them
+        // per wave and 2 k cycles of every block's prologue)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { bf16x8 v; unsigned w[4]; } u;
+            u.v = k0[kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u.w[j] ^= 0x80008000u;
+            k0[kk] = u.v;
+        }
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) negm[qb] = SS_MFMA_32x32x16(k0[kk], qr[qb][kk], negm[qb], 0, 0, 0);
+            m[qb] = -negm[qb][0];
+            lsum[qb] = (h2 == 0 && part == 0) ? 1.f : 0.f;   // (a key-split's later parts: the same offset and nothing summed yet); the two
+                                                             // half-waves' sums are added at the end
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] = part == 0 ? (float)v0[db][r >> 2][r & 3] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(0, o[NQB - 1][1][15]);
+    const int a16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int krow = ql * 128, ksw = k_swz(ql);
+    const int vrow = (4 * h2 + (a16 >> 2)) * 128, vsw = v_swz(a16 >> 2);
+    const int vsub = ((a16 & 3) & 1) * 8, vch = g16 * 2 + ((a16 & 3) >> 1);
+    int cur = 0;
+    auto tile = [&](int it, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if (it > 0) wait_vm_dyn(it + 1 < nt ? per : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(5, 0.f);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(6, 0.f);
+        if (it + 2 < nt) {
+            int ns = cur + 2; ns = ns >= GNS ? ns - GNS : ns;
+            w64_dma(rsrc, offK, offV, 1 + (it + 2) * KT, rs_bytes, lds + ns * GSTAGE, wave);
+        }
+        stamp(1, 0.f);
+        if (active) {
+            const char* sk = lds + cur * GSTAGE;
+            const char* sv = sk + KT * 128;
+            // the score chains' C operand: -m; in the last, partial tile -1e30 for the keys past T (their K / V rows read as zeros: the
+            // exponent stays -1e30, P = 0 exactly, and neither the sums nor the re-centring need a mask of their own)
+            auto chain0 = [&](int qb, int kb) -> f32x16 {
+                if constexpr (!EDGE) return negm[qb];
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2) < rem ? negm[qb][r] : NEG;
+                return c;
+            };
+            // Per tile and wave, four phases of 4 * NQB MFMAs; the exponentials of one key block run beside the matrix work of the other:
+            //   1  S(kb 0) = K0.Q'^T - m                        2  S(kb 1)  ||  P(kb 0) = exp2(S(kb 0))
+            //   3  O += V0^T.P(kb 0)  ||  P(kb 1)                4  O += V1^T.P(kb 1)
+            // Every K / V fragment is read from LDS once and feeds all of the wave's query blocks.
+            auto kfrag = [&](int kb, int kk) { return ld_bf16x8(sk + kb * 32 * 128 + krow + (((2 * kk + h2) ^ ksw) << 4)); };
+            auto vfrag = [&](int kb, int s2, int db) {
+                const int roff = (kb * 32 + 16 * s2) * 128 + vrow;
+                const int coff = (((db * 4 + vch) ^ vsw) << 4) + vsub;
+                return tr_frag(sv + roff + coff, 8 * 128);
+            };
+            // MFMA i of a phase: scores - chain step kk = i / NQB of query block i % NQB; PV - (s2, db, qb) = (i / 2 NQB, i / NQB % 2, i % NQB)
+            auto qk_step = [&](int i, int kb, const bf16x8 (&kf)[4], f32x16 (&s)[NQB]) {
+                const int kk = i / NQB, qb = i % NQB;
+                if (kk == 0) s[qb] = SS_MFMA_32x32x16(kf[0], qr[qb][0], chain0(qb, kb), 0, 0, 0);
+                else s[qb] = SS_MFMA_32x32x16(kf[kk], qr[qb][kk], s[qb], 0, 0, 0);
+            };
+            auto pv_step = [&](int i, const bf16x8 (&vf)[4], const bf16x8 (&pk)[NQB][2]) {
+                const int s2 = i / (2 * NQB), db = (i / NQB) & 1, qb = i % NQB;
+                o[qb][db] = SS_MFMA_32x32x16(vf[s2 * 2 + db], pk[qb][s2], o[qb][db], 0, 0, 0);
+            };
+            auto kload = [&](int kb, bf16x8 (&kf)[4]) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[kk] = kfrag(kb, kk);
+            };
+            auto vload = [&](int kb, bf16x8 (&vf)[4]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vf[i] = vfrag(kb, i >> 1, i & 1);
+            };
+            // the re-centring path of key block kb (wave-uniform, rare): exponents formed again; `other` = the other key block's exponents
+            // when they were formed with the old offset and are still to be used
+            auto recentre = [&](int kb, bf16x8 (&pk)[NQB][2], float (&ps)[NQB], f32x16 (*other)[NQB]) {
+                f32x16 s[NQB];
+                bf16x8 kf[4];
+                kload(kb, kf);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) qk_step(i, kb, kf, s);
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    float inc;
+                    ps[qb] = w64_recenter(s[qb], pk[qb], m[qb], negm[qb], lsum[qb], o[qb], inc, cexp);
+                    if (other)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) (*other)[qb][r] -= inc;
+                }
+            };
+            auto in_range = [&](const float (&ps)[NQB]) {
+                bool ok = ps[0] <= W64_BIG;
+#pragma unroll
+                for (int qb = 1; qb < NQB; ++qb) ok = ok && ps[qb] <= W64_BIG;
+                return __all(ok);
+            };
+            f32x16 s0[NQB], s1[NQB];
+            bf16x8 pk0[NQB][2], pk1[NQB][2];
+            bf16x8 kf[4], vf[4];
+            float acc[NQB][4], ps[NQB];
+            kload(0, kf);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) qk_step(i, 0, kf, s0);                  // phase 1
+            kload(1, kf);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[qb][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {                                       // phase 2
+                qk_step(i, 1, kf, s1);
+                softmax_w64_step<NQB, QS>(i, s0, pk0, acc, cexp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vload(0, vf);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) ps[qb] = (acc[qb][0] + acc[qb][1]) + (acc[qb][2] + acc[qb][3]);
+            stamp(2, ps[NQB - 1]);
+            if (!in_range(ps)) recentre(0, pk0, ps, &s1);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) lsum[qb] += ps[qb];
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[qb][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {                                       // phase 3
+                pv_step(i, vf, pk0);
+                softmax_w64_step<NQB, QS>(i, s1, pk1, acc, cexp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vload(1, vf);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) ps[qb] = (acc[qb][0] + acc[qb][1]) + (acc[qb][2] + acc[qb][3]);
+            stamp(3, ps[NQB - 1]);
+            if (!in_range(ps)) recentre(1, pk1, ps, nullptr);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) lsum[qb] += ps[qb];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) pv_step(i, vf, pk1);                    // phase 4
+            stamp(4, o[NQB - 1][1][15]);
+        }
+        cur = cur + 1 == GNS ? 0 : cur + 1;
+    };
+    // the key-split form of a tile (underfilled last blocks): this wave's key block only - scores, softmax, PV in sequence
+    auto tile_split = [&](int it, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if (it > 0) wait_vm_dyn(it + 1 < nt ? per : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nt) {
+            int ns = cur + 2; ns = ns >= GNS ? ns - GNS : ns;
+            w64_dma(rsrc, offK, offV, 1 + (it + 2) * KT, rs_bytes, lds + ns * GSTAGE, wave);
+        }
+        if (active) {
+            const int kb = part;
+            const char* sk = lds + cur * GSTAGE + kb * 32 * 128;
+            const char* sv = lds + cur * GSTAGE + KT * 128 + kb * 32 * 128;
+            auto scores = [&](f32x16 (&s)[NQB]) {
+                bf16x8 kf[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[kk] = ld_bf16x8(sk + krow + (((2 * kk + h2) ^ ksw) << 4));
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    f32x16 c = negm[qb];
+                    if constexpr (EDGE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2) < rem ? negm[qb][r] : NEG;
+                    }
+                    s[qb] = SS_MFMA_32x32x16(kf[0], qr[qb][0], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) s[qb] = SS_MFMA_32x32x16(kf[kk], qr[qb][kk], s[qb], 0, 0, 0);
+            };
+            f32x16 s[NQB];
+            bf16x8 pk[NQB][2], vf[4];
+            float acc[NQB][4], ps[NQB];
+            scores(s);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[qb][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) softmax_w64_step<NQB, QS>(i, s, pk, acc, cexp);
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                ps[qb] = (acc[qb][0] + acc[qb][1]) + (acc[qb][2] + acc[qb][3]);
+                ok = ok && ps[qb] <= W64_BIG;
+            }
+            if (!__all(ok)) {
+                scores(s);
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    float inc;
+                    ps[qb] = w64_recenter(s[qb], pk[qb], m[qb], negm[qb], lsum[qb], o[qb], inc, cexp);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {            // i = s2*2 + db   (behind the branch: 16 registers less across it)
+                const int roff = (16 * (i >> 1)) * 128 + vrow;
+                const int coff = ((((i & 1) * 4 + vch) ^ vsw) << 4) + vsub;
+                vf[i] = tr_frag(sv + roff + coff, 8 * 128);
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) lsum[qb] += ps[qb];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) o[qb][db] = SS_MFMA_32x32x16(vf[s2 * 2 + db], pk[qb][s2], o[qb][db], 0, 0, 0);
+        }
+        cur = cur + 1 == GNS ? 0 : cur + 1;
+    };
+    const int nint = HAS_EDGE ? nt - 1 : nt;
+    if constexpr (SPLIT) {
+        for (int it = 0; it < nint; ++it) tile_split(it, std::false_type{});
+        if constexpr (HAS_EDGE) tile_split(nt - 1, std::true_type{});
+    } else {
+        for (int it = 0; it < nint; ++it) tile(it, std::false_type{});
+        if constexpr (HAS_EDGE) tile(nt - 1, std::true_type{});
+    }
+    if constexpr (SPLIT) {
+        // merge the two partial states: part 1's [o, m, l] per lane through the (now idle) ring, lane-linear
+        float* xch = reinterpret_cast<float*>(lds) + grp * ((NQB * 34) * 64) + lane;
+        __syncthreads();                            // the ring is idle
+        if (part == 1 && active) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((qb * 34) + db * 16 + r) * 64] = o[qb][db][r];
+                xch[((qb * 34) + 32) * 64] = m[qb];
+                xch[((qb * 34) + 33) * 64] = lsum[qb];
+            }
+        }
+        __syncthreads();
+        if (part != 0) return;
+        if (active) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                const float mo = xch[((qb * 34) + 32) * 64], lo = xch[((qb * 34) + 33) * 64];
+                const float mn = fmaxf(m[qb], mo);
+                const float fa = __builtin_amdgcn_exp2f((m[qb] - mn) * cexp), fb = __builtin_amdgcn_exp2f((mo - mn) * cexp);
+                m[qb] = mn;
+                lsum[qb] = lsum[qb] * fa + lo * fb;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][db][r] = o[qb][db][r] * fa + xch[((qb * 34) + db * 16 + r) * 64] * fb;
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int q = q0 + qb * 32 + ql;
+        const float ltot = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
+        const float inv = 1.0f / ltot;
+        if (q < T) {
+            bf16_t* orow = static_cast<bf16_t*>(p.out) + ((long)b * T + q) * HD + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = db * 32 + 8 * r4 + 4 * h2;
+                    bf16x4 v = {(bf16_t)(o[qb][db][4 * r4] * inv), (bf16_t)(o[qb][db][4 * r4 + 1] * inv), (bf16_t)(o[qb][db][4 * r4 + 2] * inv),
+                                (bf16_t)(o[qb][db][4 * r4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + d) = v;
+                }
+            if (p.lse && h2 == 0) p.lse[((long)b * p.H + h) * T + q] = m[qb] * cexp + log2f(ltot);
+        }
+    }
+    if (DBG && lane == 0) {      // tools/scratch/attn_w64_timeline.py: phase sums of block (0, 0)'s waves; {start, end, HW_ID, XCC_ID, phase sums} of every block's wave 0
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.delta));
+        const unsigned long long tend = __builtin_readcyclecounter();
+        if (bh_ == 0 && qblk == 0) {
+            for (int i = 0; i < 7; ++i) d[16 + wave * 8 + i] = dbg[i];
+            d[16 + wave * 8 + 7] = tend - dbg_start;
+        }
+        if (wave == 0) {
+            const long blin = (long)bh_ * gx + qblk;
+            d[64 + blin * 12 + 0] = dbg_start;
+            d[64 + blin * 12 + 1] = tend;
+            d[64 + blin * 12 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            d[64 + blin * 12 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+            for (int i = 0; i < 7; ++i) d[64 + blin * 12 + 4 + i] = dbg[i];
+        }
+    }
+}
+
+// the key-split form as a CALL: its registers are allocated apart from the main path's (inlined next to it, the second tile loop cost the
+// main loop ~100 spilled registers)
+template <bool HAS_EDGE, bool QS>
+__device__ __forceinline__ void w64_split_block(const AttnParams& p, char* lds, int bh_, int qblk, int qbase) {
+    w64_block<1, true, HAS_EDGE, QS, false>(p, lds, bh_, qblk, qbase, 0);
+}
+
+// p.gxw blocks per (batch, head), all on one XCD (attn_block_map's scheme): the first p.gxm of them full-size main blocks, the others
+// key-split blocks of 64 rows for the rows behind (they run beside their head's main blocks and find its K / V in the XCD's L2; as a
+// launch of their own they re-read all of K and V from HBM: 805 MB, 270 us, at 256 x 12 heads of 1025 tokens).  NQB = 1: tools only.
+template <int NQB, bool HAS_EDGE, bool QS, bool DBG = false>
+__global__ __launch_bounds__(256, NQB == 2 ? 2 : 3) void attn_fwd_w64_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[GNS * GSTAGE];
+    const int gx = p.gxw;
+    const int L = blockIdx.x, slot = L >> 3;
+    const int bh_ = (slot / gx) * 8 + (L & 7), qblk = slot % gx;
+    if (bh_ >= p.B * p.H) return;
+    if (NQB == 2 && qblk >= p.gxm) w64_split_block<HAS_EDGE, QS>(p, lds, bh_, qblk - p.gxm, p.gxm * 256);
+    else w64_block<NQB, false, HAS_EDGE, QS, DBG>(p, lds, bh_, qblk, 0, gx);
+}
+
+// host side.  Full blocks of 4 x 64 query rows (plus a partial one when more than half a block is left over); the rows behind them go to
+// key-split blocks of the same launch.  variant 6 (tools): one query block per wave throughout.
+template <int NQB, bool QS, bool DBG>
+static void launch_w64_grid(const AttnParams& p, hipStream_t stream, unsigned blocks) {
+    if ((p.T - 1) % 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, true, QS, DBG>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, false, QS, DBG>), dim3(blocks), dim3(256), 0, stream, p);
+}
+
+template <bool DBG>
+static void launch_w64(const AttnParams& p0, hipStream_t stream, int nqb) {
+    AttnParams p = p0;
+    const long bh8 = ((long)(p.B * p.H + 7) / 8) * 8;
+    if (nqb != 2) {
+        p.gxm = p.gxw = (p.T + 127) / 128;
+        if (p.qscaled) launch_w64_grid<1, true, DBG>(p, stream, (unsigned)(p.gxw * bh8));
+        else launch_w64_grid<1, false, false>(p, stream, (unsigned)(p.gxw * bh8));
+        return;
+    }
+    int full = p.T / 256;
+    const int left = p.T - full * 256;
+    if (left > 64) ++full;              // (two key-split blocks - 65 rows at T = 577 - measured slower than one half-empty main block)
+    p.gxm = full;
+    p.gxw = full + ((left > 0 && left <= 64) ? 1 : 0);
+    if (p.qscaled) launch_w64_grid<2, true, DBG>(p, stream, (unsigned)(p.gxw * bh8));
+    else launch_w64_grid<2, false, false>(p, stream, (unsigned)(p.gxw * bh8));
+}
 
 // ------------------------------------------------------------------------------------------------
 // Exact-mode forward on the bf16 matrix pipe (round 3): softmax(Q K^T) V of fp32 q / k / v with every product formed from the three
@@ -2487,11 +3022,29 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
         else if (p.mask) rc = launch_fwd_res<false, true>(p, (hipStream_t)stream);
         else rc = launch_fwd_res<false, false>(p, (hipStream_t)stream);
         if (rc) return rc;
+    } else if (T >= W64_MINT && !p.mask && !p.drop_thresh && g_attn_variant != 1) {
+        // 64 queries per wave, four waves per block, every block of a (batch, head) on one XCD
+        launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2);
     } else
         if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
         else if (p.mask) hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_fwd");
+    return 0;
+}
+
+// The long-sequence 16-bit forward on operands whose q columns ALREADY carry scale * log2(e) (the caller folded the factor into the q rows
+// of the projection weight and bias before rounding them to 16 bits: the product is rounded once, as q itself would have been, where the
+// kernel's own scaling of a 16-bit q rounds a second time).  T >= 512, no mask, no dropout; lse (optional) in the log2 domain as above.
+extern "C" int simseg_attention_fwd_qscaled(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, void* stream) {
+    SS_HALF_FWD(simseg_attention_fwd_qscaled, qkv, out, lse, B, T, H, stream);
+    AttnParams p;
+    if (int rc = fill_params(p, qkv, nullptr, B, T, H, 1.0f, 0, 0.f)) return rc;
+    SS_CHECK(out, "attention_fwd_qscaled: null out");
+    SS_CHECK(T >= W64_MINT, "attention_fwd_qscaled: sequences of at least %d tokens", W64_MINT);
+    p.out = out; p.lse = lse; p.qscaled = 1;
+    launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2);
+    SS_LAUNCH_CHECK("attention_fwd_qscaled");
     return 0;
 }
 
@@ -2535,7 +3088,10 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
     const int q32 = (int)((T + 31) / 32);
     const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
+    if (T >= W64_MINT && (T - 1) % 64 == 0 && g_attn_variant != 1)      // the w64 kernel's record layout: see the end of attn_fwd_w64_kernel
+        { p.qscaled = 1; launch_w64<true>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2); }      // (timing only: q taken as pre-scaled)
+    else
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_timeline");
     return 0;
 }

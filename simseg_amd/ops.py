@@ -327,6 +327,27 @@ def cast(x, dtype, out=None):
     return out
 
 
+ATTN_QSCALED_MIN_T = 512       # W64_MINT in csrc/attn.hip
+
+
+def attention_qscale(scale=0.125):
+    """The factor attention_fwd_qscaled expects on the q columns of the projection: softmax scale times log2(e)."""
+    return float(scale) * 1.4426950408889634
+
+
+def attention_fwd_qscaled(qkv, heads, save_lse=False):
+    """Long-sequence 16-bit attention forward (T >= 512, no mask / dropout) on a projection whose q columns already carry
+    attention_qscale(scale): qkv [B,T,3*H*64] -> ctx [B,T,H*64] (include/simseg_hip.h: simseg_attention_fwd_qscaled)."""
+    require_gpu(qkv)
+    B, T, W = qkv.shape
+    if W != 3 * heads * 64 or qkv.dtype not in HALF_TYPES or T < ATTN_QSCALED_MIN_T:
+        raise ValueError("attention_fwd_qscaled: 16-bit qkv [B, T >= 512, 3*heads*64]")
+    out = torch.empty(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
+    call("simseg_attention_fwd_qscaled", ptr(_c(qkv)), ptr(out), ptr(lse), B, T, heads, stream())
+    return out, lse
+
+
 def attention_fwd_x3(qkv32, heads, scale=0.125):
     """Exact-mode attention forward on the bf16 matrix pipe: qkv32 fp32 [B, T, 3*H*64] -> ctx fp32 [B, T, H*64], every product formed from
     the three exact bf16 pieces of its fp32 operands (six leading piece products, fp32 accumulation: include/simseg_hip.h).  Evaluation

@@ -92,6 +92,32 @@ def _wt_split(w):
     return w3
 
 
+_WQS = {}
+
+
+def _wt_qscaled(w, b, adt, D):
+    """timm Attention.qkv for the long-sequence 16-bit forward (ops.attention_fwd_qscaled): the 16-bit copy of the weight [3D, D] and the
+    fp32 bias [3D] with the q rows multiplied by softmax scale * log2(e) in fp32, BEFORE the rounding to 16 bits - the projection then
+    delivers q * scale * log2(e) rounded once, and the attention kernel's exponent is its MFMA output.  Cached per parameter like _wt."""
+    key = (id(w), id(b))
+    ent = _WQS.get(key)
+    if (ent is not None and ent[0]() is w and ent[1]() is b and ent[2] == (w._version, b._version, w.data_ptr(), b.data_ptr())
+            and ent[3].dtype == adt):
+        return ent[3], ent[4]
+    c = ops.attention_qscale(64 ** -0.5)
+    ws = w.detach().float().clone()
+    ws[:D] *= c
+    bs = b.detach().float().clone()
+    bs[:D] *= c
+    w16 = ops.cast(ws.contiguous(), adt)
+    if isinstance(w, torch.nn.Parameter):
+        if len(_WQS) > 1024:
+            for k in [k for k, e in _WQS.items() if e[0]() is None]:
+                del _WQS[k]
+        _WQS[key] = (weakref.ref(w), weakref.ref(b), (w._version, b._version, w.data_ptr(), b.data_ptr()), w16, bs)
+    return w16, bs
+
+
 def _fwd_gemm(x2d, w, adt, saving, **kw):
     """x2d @ w^T for an nn.Linear weight `w` [out, in] in the forward pass: the activation-dtype kernel, or - exact mode, nothing saved for
     a backward, enough tiles - the split-bf16 form of the same fp32 product."""
@@ -483,6 +509,16 @@ class ViTBlockFn(_GradAwareFn):
         x = x.contiguous()
         save = _saving(ctx)
         ln1, _, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), 1e-6, out_dtype=adt, save_stats=save)
+        if not save and adt != F32 and T >= ops.ATTN_QSCALED_MIN_T and os.environ.get("SIMSEG_AMD_QSCALED", "1") != "0":
+            # evaluation, 16-bit, long sequences (384^2 / 512^2 windows): the 64-queries-per-wave forward on a projection that already
+            # carries the softmax scale (SIMSEG_AMD_QSCALED=0: A/B runs on the kernel that scales q itself)
+            qw_s, qb_s = _wt_qscaled(qw, qb, adt, D)
+            qkv = ops.gemm(ln1.view(-1, D), qw_s, bias=qb_s)
+            att, _ = ops.attention_fwd_qscaled(qkv.view(B, T, 3 * D), heads)
+            x1 = _fwd_gemm(att.view(-1, D), pw, adt, False, bias=pb.detach(), residual=x.view(-1, D), out_dtype=F32)
+            ln2, _, _, _ = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6, out_dtype=adt, save_stats=False)
+            act = _fwd_gemm(ln2, f1w, adt, False, bias=f1b.detach(), act=1)
+            return _fwd_gemm(act, f2w, adt, False, bias=f2b.detach(), residual=x1, out_dtype=F32).view(B, T, D)
         if not save:        # evaluation: no operand is kept (exact mode: large problems go through the split-bf16 form of the fp32 products)
             qkv = _fwd_gemm(ln1.view(-1, D), qw, adt, False, bias=qb.detach())
             if adt == F32 and _SPLIT_FP32 != "0" and (_SPLIT_FP32 == "1" or (T >= 512 and B * heads >= 128)):

@@ -772,6 +772,88 @@ def test_attention_deferred_rescale_branch(ops, T):
     _close(ops.attention_bwd(qkv, out, dout, lse, H, mask), x.grad, 2e-2, f"attention bwd with late maxima T={T}")
 
 
+def _lse_ref(qkv, H, scale=0.125):
+    B, T, _ = qkv.shape
+    q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    return torch.logsumexp(q @ k.transpose(-1, -2) * scale, -1) / math.log(2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,H", [(3, 512, 2), (2, 513, 3), (2, 577, 2), (3, 600, 3), (11, 1025, 1), (1, 1024, 3), (2, 1089, 2), (1, 1153, 2), (1, 2305, 1)])
+def test_attention_fwd_long_sequences(ops, B, T, H, dtype):
+    """The 64-queries-per-wave forward (T >= 512, no mask / dropout; csrc/attn.hip attn_fwd_w64_kernel): class-token key as the softmax's
+    start, full tiles from key 1, the masked last tile ((T - 1) % 64 != 0), blocks with idle waves, the key-split block for <= 64 leftover
+    rows (513, 577 -> one main block more; 1025, 1089, 2305 -> key-split), (batch x head) counts that are not multiples of the 8 XCDs -
+    against fp32 torch on the same 16-bit operands, and against the ring kernel it replaces (variant 1)."""
+    qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.3, dtype=dtype)
+    want = _attn_ref(qkv, H, None, 0.125)
+    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3
+    _close(out, want, tol, f"attention fwd T={T} {dtype}")
+    _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
+    ops.set_attention_variant(1)
+    try:
+        ring, _ = ops.attention_fwd(qkv, H, None)
+    finally:
+        ops.set_attention_variant(0)
+    _close(out, ring, tol, "w64 against the ring kernel")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,H", [(2, 1025, 3), (1, 577, 2), (2, 700, 2), (3, 512, 1)])
+def test_attention_fwd_qscaled(ops, B, T, H, dtype):
+    """simseg_attention_fwd_qscaled: the q columns carry scale * log2(e) BEFORE their rounding to 16 bits (the towers fold the factor into
+    timm Attention.qkv's q rows).  Reference: exact attention of the rounded operands with the factor divided out again - the kernel's
+    exponent is its MFMA output, nothing is rounded twice, so the log-sum-exp agrees to fp32 rounding."""
+    c = ops.attention_qscale(0.125)
+    q32 = _rand(B, T, 3, H, 64, seed=T + 7, scale=1.3)
+    q32[:, :, 0] *= c
+    qkv = q32.view(B, T, 3 * H * 64).to(dtype)
+    back = qkv.float().view(B, T, 3, H, 64).clone()
+    back[:, :, 0] /= c
+    back = back.view(B, T, 3 * H * 64)
+    out, lse = ops.attention_fwd_qscaled(qkv, H, save_lse=True)
+    _close(out, _attn_ref(back, H, None, 0.125), 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3, f"attention fwd qscaled T={T} {dtype}")
+    _close(lse, _lse_ref(back, H), 1e-5, "lse (log2)")
+    with pytest.raises(Exception):
+        ops.attention_fwd_qscaled(qkv[:, :300].contiguous(), H)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T", [1025, 700])
+def test_attention_fwd_long_recentre_branch(ops, T, dtype):
+    """The long-sequence forward keeps a per-row offset that only has to keep the probabilities representable, and raises it - O, l rescaled,
+    P recomputed from re-formed scores - when a half-row's sum over a key block leaves [0, 2^14] (fp16) / [0, 2^30] (bf16): a wave-uniform
+    branch that bounded random scores never take.  Force it in every phase: keys made collinear with a few queries so that those rows'
+    scores jump by 40-120 (log2 units) above the class-token score in the first, a middle and the last tile, in the first and the second
+    32-key block, for rows of a main block, of a key-split block (T = 1025: row 1024) and of the masked last tile (T = 700); one row's
+    scores overflow fp32 exponentials outright (2^200)."""
+    B, H = 2, 2
+    qkv = _rand(B, T, 3 * H * 64, seed=T + 11, scale=0.7, dtype=dtype)
+    v5 = qkv.view(B, T, 3, H, 64)
+    spikes = ((3, 5, 9.0), (100, 40, 14.0), (T - 1, T // 2 + 3, 11.0), (T - 1, T - 2, 16.0), (300, T - 40, 20.0), (511, 700 - 37 if T > 700 else 600, 12.0),
+              (64, 33 + 64 * 7, 40.0))
+    for j, (qi, ki, amp) in enumerate(spikes):
+        v5[j % B, ki, 1, j % H] = (v5[j % B, qi, 0, j % H].float() * amp).to(dtype)
+    q, k, _ = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) * 0.125 / math.log(2)
+    assert float(sc.max()) > 150.0 and float((sc.amax(-1) - sc[..., 0]).max()) > 100.0       # far above the class-token score, beyond 2^127
+    want = _attn_ref(qkv, H, None, 0.125)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3
+    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+    assert torch.isfinite(out.float()).all()
+    _close(out, want, tol, f"long forward with late maxima T={T}")
+    _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
+    c = ops.attention_qscale(0.125)
+    qs = qkv.clone()
+    qs.view(B, T, 3, H, 64)[:, :, 0] = (v5[:, :, 0].float() * c).to(dtype)
+    back = qs.float().view(B, T, 3, H, 64).clone()
+    back[:, :, 0] /= c
+    out2, lse2 = ops.attention_fwd_qscaled(qs, H, save_lse=True)
+    _close(out2, _attn_ref(back.view(B, T, -1), H, None, 0.125), tol, f"qscaled forward with late maxima T={T}")
+    _close(lse2, _lse_ref(back.view(B, T, -1), H), 1e-5, "lse (log2)")
+
+
 @pytest.mark.parametrize("T", [1, 33, 64, 65, 129, 1025])
 def test_attention_edge_lengths(ops, T):
     """Tile edges (one token, one over a 32 / 64 boundary, the 512^2 window) with a (batch x head) count that is not a multiple of
