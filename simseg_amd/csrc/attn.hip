@@ -1077,8 +1077,10 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
             int ns = cur + 2; ns = ns >= GNS ? ns - GNS : ns;
             w64_dma(rsrc, offK, offV, 1 + (it + 2) * KT, rs_bytes, lds + ns * GSTAGE, wave);
         }
-        if (active) {
-            const int kb = part;
+        if (active)
+#pragma unroll
+        for (int kbi = 0; kbi < (SPLIT ? 1 : 2); ++kbi) {      // (not SPLIT - one query block per wave, tools only: both key blocks in sequence)
+            const int kb = SPLIT ? part : kbi;
             const char* sk = lds + cur * GSTAGE + kb * 32 * 128;
             const char* sv = lds + cur * GSTAGE + KT * 128 + kb * 32 * 128;
             auto scores = [&](f32x16 (&s)[NQB]) {
@@ -1141,7 +1143,7 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
         cur = cur + 1 == GNS ? 0 : cur + 1;
     };
     const int nint = HAS_EDGE ? nt - 1 : nt;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT || NQB == 1) {
         for (int it = 0; it < nint; ++it) tile_split(it, std::false_type{});
         if constexpr (HAS_EDGE) tile_split(nt - 1, std::true_type{});
     } else {

@@ -344,6 +344,7 @@ def attention_fwd_qscaled(qkv, heads, save_lse=False):
         raise ValueError("attention_fwd_qscaled: 16-bit qkv [B, T >= 512, 3*heads*64]")
     out = torch.empty(B, T, heads * 64, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32) if save_lse else None
+    _push_variant("attention")
     call("simseg_attention_fwd_qscaled", ptr(_c(qkv)), ptr(out), ptr(lse), B, T, heads, stream())
     return out, lse
 

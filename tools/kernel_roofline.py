@@ -52,6 +52,19 @@ def main():
                 fl = 10.0 * B * H * T * T * 64
                 out[f"attn_bwd_bf16_{name}"] = {"B": B, "T": T, "H": H, "ms": round(s * 1e3, 4), "tflops": round(fl / s / 1e12, 1),
                                                 "frac_mfma_peak": round(fl / s / PEAK[dt], 4)}
+    # the evaluation towers' form of the long-sequence forward (round 6): q columns carry scale * log2(e) (towers._wt_qscaled),
+    # simseg_attention_fwd_qscaled; both 16-bit types, the seg-eval batch sizes; fp16 runs through the same source compiled with -DSS_HALF
+    c = ops.attention_qscale(0.125)
+    for dt, tdt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        for name, B, T, H in (("vitb_512", 16, 1025, 12), ("vitb_512", 63, 1025, 12), ("vitb_512", 256, 1025, 12), ("vitb_384", 256, 577, 12),
+                              ("vits_512", 256, 1025, 6)):
+            qkv = torch.randn(B, T, 3 * H * 64, device="cuda", generator=g)
+            qkv.view(B, T, 3, H * 64)[:, :, 0] *= c
+            qkv = qkv.to(tdt)
+            s = timeit(lambda: ops.attention_fwd_qscaled(qkv, H))
+            fl = 4.0 * B * H * T * T * 64
+            out[f"attn_fwd_qscaled_{dt}_{name}_B{B}"] = {"B": B, "T": T, "H": H, "ms": round(s * 1e3, 4), "tflops": round(fl / s / 1e12, 1),
+                                                          "frac_mfma_peak": round(fl / s / PEAK["bf16"], 4)}
     for k, v in out.items():
         print(k, json.dumps(v))
 

@@ -17,7 +17,9 @@ def t(fn, it=20):
     return e0.elapsed_time(e1) / it
 
 
+import os
 H = 12
+ops.set_attention_variant(int(os.environ.get("ATTN_VARIANT", "0")))
 c = ops.attention_qscale(0.125)
 out = []
 for dtype in (torch.bfloat16, torch.float16):
