@@ -658,11 +658,14 @@ class ClockSampler:
                 "source": getattr(self, "source", None)}
 
 
-def guarded(name, fn, *a, **kw):
-    """A secondary leg must not take the headline down with it: its exception becomes {"error": ...} in the line (and a log entry).  The legs'
-    device work is the same on every rank, so a failure is symmetric and no rank is left waiting in a collective."""
+def guarded(name, fn, *a, all_ranks=True, **kw):
+    """A secondary leg must not take the headline down with it: its exception becomes {"error": ...} in the line (and a log entry).  With
+    N > 1 ranks the verdict is agreed on after the leg (one all-reduce of an ok flag): a leg that failed on ANY rank is reported as failed by
+    every rank, so no rank carries on with results the others do not have.  (A rank that dies INSIDE a leg's collective still leaves the
+    others waiting there until the process group's timeout - the legs' device work is the same on every rank, which makes that unlikely.)"""
+    res, err = None, None
     try:
-        return fn(*a, **kw)
+        res = fn(*a, **kw)
     except Exception as e:       # noqa: BLE001
         import traceback
         log(f"leg {name} FAILED: {e!r}\n{traceback.format_exc()}")
@@ -670,7 +673,16 @@ def guarded(name, fn, *a, **kw):
             torch.cuda.synchronize()
         except Exception:       # noqa: BLE001
             pass
-        return {"error": f"{type(e).__name__}: {e}"[:500]}
+        err = {"error": f"{type(e).__name__}: {e}"[:500]}
+    if all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:      # (all_ranks=False: a leg only rank 0 runs)
+        try:
+            bad = torch.tensor([0 if err is None else 1], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad) and err is None:
+                err = {"error": f"leg {name} failed on another rank"}
+        except Exception as e:       # noqa: BLE001
+            err = err or {"error": f"leg {name}: ranks could not agree on its outcome ({type(e).__name__})"}
+    return res if err is None else err
 
 
 def self_launch(n):
@@ -769,6 +781,36 @@ def main():
             log(f"WARNING: two ranks share a device: {ranks}")
     else:
         pg_info["ranks"] = [me]
+    # Preflight (N > 1 ranks, or a one-rank group with SIMSEG_FORCE_COLLECTIVES=1): every collective of the step once with a value check, then
+    # a few timed repetitions each (the isolated rates of roofline.comm).  A wrong value, or two ranks on one device under nccl, ends the run
+    # HERE with a JSON error line and a non-zero exit code - before anything is timed.
+    comm_probe = None
+    from simseg_amd.parallel import force_collectives
+    if dist.is_initialized() and (world > 1 or force_collectives()):
+        from simseg_amd import commcheck
+        if os.environ.get("SIMSEG_BENCH_SABOTAGE_PREFLIGHT") == "1" and rank == world - 1:      # tests: this rank's all-reduce returns wrong values
+            _real_all_reduce = dist.all_reduce
+
+            def _broken_all_reduce(t, *a, **kw):
+                w = _real_all_reduce(t, *a, **kw)
+                if t.is_floating_point():
+                    t.add_(1.0)
+                return w
+            dist.all_reduce = _broken_all_reduce
+        try:
+            comm_probe = commcheck.preflight(dev, args.pairs_per_gpu, ranks_info=pg_info["ranks"])
+            log(f"communication preflight ok: { {k: (v.get('busbw_GBps'), v['ok']) for k, v in comm_probe.items()} }")
+        except commcheck.PreflightError as e:
+            log(f"communication preflight FAILED: {e}")
+            if rank == 0:
+                os.write(_JSON_FD, (json.dumps({"metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": None, "unit": "pairs/s",
+                                                "n_gpus": world, "error": f"communication preflight failed: {e}"[:800],
+                                                "config": {"process_group": pg_info}}) + "\n").encode())
+            try:
+                dist.destroy_process_group()
+            except Exception:       # noqa: BLE001
+                pass
+            sys.exit(3)
     from simseg.models import PIPELINE
     torch.manual_seed(1234)
     model = build(cfg.model.name, cfg, PIPELINE).to(dev).train()
@@ -964,6 +1006,34 @@ def main():
             set_mode(HEAD)
             step()                           # (weight copies of the headline type are back before the instrumented step)
 
+    # ---- the same step with every collective replaced by a local stand-in of the same shapes (N > 1 ranks, or forced collectives on one):
+    # buffers, hooks, events and the communication stream stay, no byte travels.  step(N) - this = the communication the step did not hide.
+    # Last of the training legs: without the exchange the ranks' weights drift apart, which nothing after it depends on.
+    no_comm = None
+    comm_sizes = (sync.flat.numel() * 4, len(sync.buckets)) if sync is not None else None
+    if sync is not None and comm_probe is not None:
+        from simseg_amd import heads as _heads
+        _heads.LOCAL_STANDIN, sync.skip_collectives = True, True
+        try:
+            for _ in range(2):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el5 = torch.tensor([time.perf_counter() - t3], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(el5, op=dist.ReduceOp.MAX)
+            no_comm = {"ms_per_step": round(1e3 * float(el5) / args.steps, 3), "pairs_per_s": round(world * B * args.steps / float(el5), 2)}
+        finally:
+            _heads.LOCAL_STANDIN, sync.skip_collectives = False, False
+        step()
+
     # ---- roofline of the dominant kernel: one extra instrumented step, events around every GEMM launch -------------
     # The timed steps run the two towers on two HIP streams (their kernels share the GPU, so a per-kernel duration is not
     # that kernel's own speed); the instrumented step runs them on ONE stream so that each launch is timed alone.
@@ -987,7 +1057,7 @@ def main():
     ops.PROFILE = None
     attn_roofline = attention_roofline(dev, B, args.img, L, dtype=HALF[HEAD]) if rank == 0 else {}
     if rank == 0:
-        attn_roofline.update(guarded("layernorm roofline", layernorm_roofline, dev, B, args.img, dim, dtype=HALF[HEAD]) or {})
+        attn_roofline.update(guarded("layernorm roofline", layernorm_roofline, dev, B, args.img, dim, dtype=HALF[HEAD], all_ranks=False) or {})
     os.environ["SIMSEG_AMD_COMPUTE"] = "bf16"          # (the evaluation legs below choose their own type)
     del net, model, opt, batches
     torch.cuda.empty_cache()
@@ -1093,6 +1163,24 @@ def main():
         per_class["all_bf16_gemms"] = {"launches": sum(v[0] for k, v in agg.items() if not k.startswith("f32")), "ms": round(1e3 * gsec, 3),
                                        "tflops": round(gfl / gsec / 1e12, 1), "frac": round(gfl / gsec / PEAK_BF16, 4)}
         per_class.update(attn_roofline)
+        comm_block = None
+        if comm_probe is not None and comm_sizes is not None:
+            from simseg_amd import commcheck
+            comm_block = commcheck.comm_roofline(world, B, comm_sizes[0], comm_sizes[1], comm_probe, 1e3 * elapsed / args.steps,
+                                                 no_comm["ms_per_step"] if no_comm else None, process_group=pg_info)
+            comm_block["preflight"] = comm_probe
+
+        def _pick(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        # the figures a reader of the parsed line (metric / value / config / roofline only) should still see
+        secondary = {f"train_pairs_per_s_{OTHER}": other_leg["pairs_per_s"] if other_leg else None,
+                     "seg_eval_bf16_windows_per_s": _pick(seg, "bf16", "windows_per_s"),
+                     "seg_eval_bf16_crf_windows_per_s": _pick(seg, "bf16_crf", "windows_per_s"),
+                     "seg_eval_vit_s_512_bf16_windows_per_s": _pick(seg, "vit_s_512_bf16", "windows_per_s"),
+                     "seg_slide_512x1024_bf16_images_per_s": _pick(seg, "slide_512x1024", "bf16", "images_per_s"),
+                     "seg_slide_512x1024_bf16_crf_images_per_s": _pick(seg, "slide_512x1024", "bf16_crf", "images_per_s")}
         out = {
             "metric": "image-text pairs/sec (train) + seg images/sec (eval), ViT-B", "value": round(value, 2), "unit": "pairs/s",
             "value_is": "training image-text pairs/s over all ranks; the zero-shot-seg eval rate is reported in seg_eval", "n_gpus": world,
@@ -1106,7 +1194,7 @@ def main():
                                    f"{B} pairs/GPU, {args.img}x{args.img} images, {L}-token captions (BASELINE configs[2], weak-scaled)",
                        "image_encoder": args.tag, "text_encoder": "bert-base-uncased", "global_batch": world * B,
                        "pairs_per_gpu": B, "seq_len": L, "img_size": args.img, "parallelism": f"dp{world}",
-                       "process_group": pg_info, "batches_rotated": NB,
+                       "process_group": pg_info, "batches_rotated": NB, "secondary_figures": secondary,
                        "caption_lengths": ("host-side token counts travel with the batch (no host read in the step)" if HOST_LENGTHS
                                            else "derived from the device mask (one host read per step)"),
                        "gradient_sync": ((f"simseg_amd.parallel.GradSync ({dp})" + ((" [forced on one rank: every collective issued on the one-rank " + str(pg_info["backend"]) + " group]" if os.environ.get("SIMSEG_FORCE_COLLECTIVES", "0") == "1"
@@ -1129,7 +1217,7 @@ def main():
                          "flops_per_launch_avg": fl / cnt,
                          "measured": "one instrumented step with both towers on one stream (each launch alone on the GPU); the timed "
                                      "steps overlap the two towers on two streams" if two_streams else "one instrumented step",
-                         "clocks_during_timed_steps": clock_info,
+                         "clocks_during_timed_steps": clock_info, "measured_on": me, "comm": comm_block,
                          "frac_of_peak_at_measured_clock": (round(achieved / clock_info["dense_bf16_peak_at_this_clock_tflops"], 4)
                                                             if clock_info else None),
                          # what bounds these launches (measured once per round, not in this process): the same kernels on ZERO operands - same

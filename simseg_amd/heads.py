@@ -11,6 +11,27 @@ from . import ops
 F32 = torch.float32
 
 
+# Benchmarks only (bench.py's "communication-free" leg at N > 1 ranks): every embedding exchange is replaced by a LOCAL stand-in of the
+# same shapes - the gathered matrix is this rank's rows repeated `world` times, the reduce-scatter keeps this rank's slice - so the step
+# computes everything it computes with the exchange (the [Bl, W * Bl] similarity blocks included) and moves no byte between ranks.  The
+# numbers are not the global loss's; what the leg is for is step(N) - step(N, stand-ins) = the communication the step could not hide.
+LOCAL_STANDIN = False
+
+
+def _all_gather(out, t, group, async_op=False):
+    if LOCAL_STANDIN:
+        out.view((-1,) + tuple(t.shape)).copy_(t.unsqueeze(0).expand((out.shape[0] // t.shape[0],) + tuple(t.shape)))
+        return None
+    return dist.all_gather_into_tensor(out, t, group=group, async_op=async_op)
+
+
+def _reduce_scatter(own, grad, group):
+    if LOCAL_STANDIN:
+        own.copy_(grad.view((-1,) + tuple(own.shape))[dist.get_rank(group)])
+        return
+    dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=group)
+
+
 def _one(world):
     """The one-rank shortcut applies (see parallel.force_collectives: SIMSEG_FORCE_COLLECTIVES=1 keeps the collectives at world size 1)."""
     from .parallel import force_collectives
@@ -32,7 +53,7 @@ def prefetch_gather(tensor, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(group)
-    if _one(world):
+    if _one(world) or LOCAL_STANDIN:
         return
     t = tensor.detach().contiguous()
     out = torch.empty(_gathered_shape(t, world), device=t.device, dtype=t.dtype)
@@ -88,7 +109,7 @@ class GatherLayer(Function):
         if _one(world):
             out.copy_(tensor)
         else:
-            dist.all_gather_into_tensor(out, tensor, group=group)
+            _all_gather(out, tensor, group)
         return out
 
     @staticmethod
@@ -98,7 +119,7 @@ class GatherLayer(Function):
         if _one(world):
             return grad.clone(), None, None
         own = torch.empty((ctx.bl,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
-        dist.reduce_scatter_tensor(own, grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        _reduce_scatter(own, grad, ctx.group)
         return own, None, None
 
 
@@ -112,7 +133,7 @@ def all_gather_rows(tensor, group):
     if _one(world):
         return tensor
     out = torch.empty(_gathered_shape(tensor, world), device=tensor.device, dtype=tensor.dtype)
-    dist.all_gather_into_tensor(out, tensor, group=group)
+    _all_gather(out, tensor, group)
     return out
 
 
@@ -172,10 +193,10 @@ class ClipLossFn(Function):
             txt_g = _take_prefetched(txt, group)
             if img_g is None:
                 img_g = torch.empty(_gathered_shape(img32, world), device=img.device, dtype=F32)
-                dist.all_gather_into_tensor(img_g, img32, group=group)
+                _all_gather(img_g, img32, group)
             if txt_g is None:
                 txt_g = torch.empty(_gathered_shape(txt32, world), device=txt.device, dtype=F32)
-                dist.all_gather_into_tensor(txt_g, txt32, group=group)
+                _all_gather(txt_g, txt32, group)
             img_g, txt_g = img_g.float(), txt_g.float()
         else:
             img_g, txt_g = img32, txt32
@@ -218,7 +239,7 @@ class ClipLossFn(Function):
                 else:
                     dimg_g = ops.gemm(dst_t, txt_t)                          # [Bg, P]: every rank's rows; this rank keeps the sum of its own
                     own = torch.empty_like(dimg)
-                    dist.reduce_scatter_tensor(own, dimg_g, op=dist.ReduceOp.SUM, group=ctx.group)
+                    _reduce_scatter(own, dimg_g, ctx.group)
                     dimg = dimg + own
         if need_txt:
             dtxt = ops.gemm(ds[1], imgg_t)                                   # dS_t . img_g
@@ -228,7 +249,7 @@ class ClipLossFn(Function):
                 else:
                     dtxt_g = ops.gemm(dsi_t, img_t)
                     own = torch.empty_like(dtxt)
-                    dist.reduce_scatter_tensor(own, dtxt_g, op=dist.ReduceOp.SUM, group=ctx.group)
+                    _reduce_scatter(own, dtxt_g, ctx.group)
                     dtxt = dtxt + own
         return dimg, dtxt, (dt.reshape(()) if need_t else None), None, None, None, None
 

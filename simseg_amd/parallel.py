@@ -67,6 +67,7 @@ class GradSync:
             for i in bk["members"]:
                 self._bucket_of[i] = b
         self._on = False
+        self.skip_collectives = False         # benchmarks only (bench.py's communication-free leg): the whole machinery, no all-reduce
         self._comm = None
         self._handles = []
         self._armed = False
@@ -248,7 +249,7 @@ class GradSync:
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._gather_bucket(b)
-                if self._world() > 1 or force_collectives():
+                if (self._world() > 1 or force_collectives()) and not self.skip_collectives:
                     self._reduce(b)
         return hook
 
@@ -266,13 +267,13 @@ class GradSync:
             self._copied += len(dst)
             if dst:
                 torch._foreach_copy_(dst, src)
-            if world > 1 or force_collectives():
+            if (world > 1 or force_collectives()) and not self.skip_collectives:
                 dist.all_reduce(self.flat, group=self.group)
         else:
             for b, left in enumerate(self._pending):
                 if left:                           # a bucket with parameters that got no gradient this step (they count as zero)
                     self._gather_bucket(b)
-                    if world > 1 or force_collectives():
+                    if (world > 1 or force_collectives()) and not self.skip_collectives:
                         self._reduce(b)
             for w in self._works:
                 w.wait()                           # the current stream waits for the collective (RCCL: no host block)

@@ -267,3 +267,90 @@ def test_loss_and_gradients_do_not_depend_on_the_number_of_ranks():
         for r in range(world):
             for got, ref in zip(out[r], want):
                 np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6, err_msg=f"world {world} rank {r}")
+
+
+# ---- round 6: the communication preflight and the bench line's roofline.comm block (simseg_amd/commcheck.py) ------------------------------
+def _commcheck_worker(rank, world, port, q, sabotage):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simseg_amd import commcheck, heads
+    from simseg_amd.parallel import GradSync
+    dev = torch.device("cpu")
+    res = {}
+    if sabotage and rank == 1:          # one rank's all-reduce returns garbage: EVERY rank's preflight must raise
+        real = dist.all_reduce
+
+        def broken(t, *a, **kw):
+            w = real(t, *a, **kw)
+            if t.dtype == torch.float32:
+                t.add_(1.0)
+            return w
+        dist.all_reduce = broken
+    try:
+        probe = commcheck.preflight(dev, 8, bucket_bytes=1 << 16, iters=2,
+                                    ranks_info=[{"rank": r, "device": f"cpu:{r}"} for r in range(world)])
+        res["probe"] = probe
+    except commcheck.PreflightError as e:
+        res["error"] = str(e)
+    if not sabotage:
+        # the local stand-ins of the bench's communication-free leg: same shapes, nothing exchanged
+        x = torch.full((3, 4), float(rank + 1), requires_grad=True)
+        heads.LOCAL_STANDIN = True
+        try:
+            gathered = heads.GatherLayer.apply(x, dist.group.WORLD, rank)
+            (gathered * torch.arange(1, world * 3 + 1, dtype=torch.float32)[:, None]).sum().backward()
+        finally:
+            heads.LOCAL_STANDIN = False
+        res["standin"] = (gathered.detach().clone(), x.grad.clone())
+        lin = torch.nn.Linear(4, 3)
+        sync = GradSync(lin.parameters())
+        sync.skip_collectives = True
+        lin(torch.full((2, 4), float(rank + 1))).sum().backward()
+        sync()
+        res["skip_grad"] = lin.weight.grad.clone()
+        sync.close()
+        res["block"] = commcheck.comm_roofline(world, 8, 1000 * 4, 3, probe, 90.0, 86.5, process_group={"backend": "gloo"})
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sabotage", [False, True])
+def test_comm_preflight_and_roofline_block_two_ranks(sabotage):
+    """Every collective of the step once with a value check (all-gather / reduce-scatter of the embeddings, a gradient bucket's all-reduce,
+    the int64 MIN / MAX check), the same verdict on every rank - also when only ONE rank's collective returns wrong values; the local
+    stand-ins of the communication-free leg keep the shapes and exchange nothing; the roofline.comm arithmetic."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_commcheck_worker, args=(r, world, port, q, sabotage)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if sabotage:
+        assert all("error" in got[r] for r in range(world)), got
+        assert "wrong values" in got[1]["error"] and "another rank" in got[0]["error"]
+        return
+    for r in range(world):
+        pr = got[r]["probe"]
+        assert set(pr) == {"C1_embedding_all_gather", "C2_embedding_grad_reduce_scatter", "C4_gradient_bucket_all_reduce", "bucket_cut_check_int64_min_max"}
+        assert all(v["ok"] for v in pr.values())
+        assert pr["C1_embedding_all_gather"]["wire_bytes_per_rank"] == 8 * 512 * 4                 # (W - 1) blocks
+        assert pr["C2_embedding_grad_reduce_scatter"]["wire_bytes_per_rank"] == 8 * 512 * 4         # (W - 1) / W of W blocks
+        assert pr["C4_gradient_bucket_all_reduce"]["wire_bytes_per_rank"] == (1 << 16)              # 2 (W - 1) / W
+        g, gx = got[r]["standin"]
+        assert g.shape == (6, 4) and torch.all(g == float(r + 1))                                    # this rank's rows, twice
+        want = torch.arange(1, 7, dtype=torch.float32).view(2, 3)[r]
+        assert torch.equal(gx, want[:, None].expand(3, 4))                                           # this rank's slice of the gradient, no sum
+        assert torch.all(got[r]["skip_grad"] == 2.0 * (r + 1) / world)                               # the LOCAL gradient (not the sum over ranks) times 1 / W
+        blk = got[r]["block"]
+        assert blk["exposed_communication_ms_per_step"] == 3.5 and blk["world_size"] == 2 and blk["peak"] == 7 * 153.0
+        assert blk["per_class"]["C4_gradient_all_reduce"]["wire_bytes_per_rank_step"] == 4000 and blk["per_class"]["C4_gradient_all_reduce"]["per_step"] == 3
+        assert blk["wire_bytes_per_rank_step"] == 4000 + 2 * 8 * 512 * 4 + 2 * 8 * 512 * 4
+        assert blk["achieved"] == round(blk["wire_bytes_per_rank_step"] / 3.5e-3 / 1e9, 1)

@@ -389,6 +389,69 @@ def test_bench_self_launches_two_ranks_on_rccl():
     assert line["n_gpus"] == 2 and pg["backend"] == "nccl" and pg["world_size"] == 2 and "warning" not in pg, pg
     assert len({r["device"] for r in pg["ranks"]}) == 2
     assert line["config"]["global_batch"] == 128 and line["value"] > 0
+    _check_comm_block(line, world=2)
+
+
+def _check_comm_block(line, world):
+    """roofline.comm of an N-rank (or forced one-rank) bench line: bytes per rank-step of C1 / C2 / C4, the preflight's isolated rates against
+    the xGMI peak, the communication-free leg and what it exposes."""
+    comm = line["roofline"]["comm"]
+    assert comm is not None and comm["bound"] == "xgmi" and comm["peak"] == 7 * 153.0 and comm["world_size"] == world
+    pre = comm["preflight"]
+    assert all(v["ok"] for v in pre.values()) and {"C1_embedding_all_gather", "C2_embedding_grad_reduce_scatter", "C4_gradient_bucket_all_reduce"} <= set(pre)
+    pc = comm["per_class"]
+    bl = line["config"]["pairs_per_gpu"]
+    assert pc["C1_embedding_all_gather"]["wire_bytes_per_rank_step"] == 2 * (world - 1) * bl * 512 * 4
+    assert pc["C2_embedding_grad_reduce_scatter"]["wire_bytes_per_rank_step"] == 2 * (world - 1) * bl * 512 * 4
+    gb = pc["C4_gradient_all_reduce"]["payload_bytes_per_step"]
+    assert 7.5e8 < gb < 8.2e8 and pc["C4_gradient_all_reduce"]["wire_bytes_per_rank_step"] == 2 * (world - 1) * gb // world       # ViT-B + BERT-base + heads in fp32
+    assert pc["C4_gradient_all_reduce"]["per_step"] == line["config"]["gradient_sync_detail"]["buckets"]
+    assert comm["ms_per_step_with_local_stand_ins"] is not None and comm["ms_per_step"] == line["ms_per_step"]
+    assert abs(comm["exposed_communication_ms_per_step"] - (comm["ms_per_step"] - comm["ms_per_step_with_local_stand_ins"])) < 2e-3
+    assert comm["process_group"]["world_size"] == world
+
+
+def test_bench_comm_roofline_on_one_rank_rccl_group():
+    """The N > 1 form of bench.py on the one-GPU box: a one-rank `nccl` (RCCL) group with SIMSEG_FORCE_COLLECTIVES=1 runs the preflight (every
+    collective once, values checked), the headline with every collective issued, the communication-free leg, and reports roofline.comm."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SIMSEG_FORCE_COLLECTIVES="1", SIMSEG_BENCH_FORCE_SYNC="1", SIMSEG_BENCH_OTHER_DTYPE_LEG="0",
+               SIMSEG_BENCH_GELU16_LEG="0", SIMSEG_AMD_PACKED_TEXT="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "2", "--pairs-per-gpu", "64", "--no-seg",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["config"]["process_group"]["backend"] == "nccl" and line["n_gpus"] == 1
+    _check_comm_block(line, world=1)
+    assert "communication preflight ok" in out.stderr
+
+
+def test_bench_two_ranks_gloo_bringup_reports_comm_roofline():
+    """Two ranks sharing the one GPU over gloo (`SIMSEG_DIST_BACKEND=gloo SIMSEG_BENCH_DEVICE=0 python bench.py --gpus 2`, self-launched): the
+    preflight passes on two ranks, the line carries roofline.comm with two ranks' traffic; with a sabotaged collective
+    (SIMSEG_BENCH_SABOTAGE_PREFLIGHT=1: rank 1 perturbs what its all-reduce returns) the run ends before anything is timed with a JSON error
+    line and a non-zero exit code."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SIMSEG_DIST_BACKEND="gloo", SIMSEG_BENCH_DEVICE="0", SIMSEG_BENCH_OTHER_DTYPE_LEG="0",
+               SIMSEG_BENCH_GELU16_LEG="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs-per-gpu", "32", "--no-seg", "--no-cpu-baseline"]
+    bad = subprocess.run(cmd, env=dict(env, SIMSEG_BENCH_SABOTAGE_PREFLIGHT="1"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+    err = json.loads(bad.stdout.strip().splitlines()[-1])
+    assert err["value"] is None and "communication preflight failed" in err["error"] and err["n_gpus"] == 2
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["process_group"]["backend"] == "gloo"
+    _check_comm_block(line, world=2)
 
 
 def _worker_seg_sharded(rank, world, port, backend, q):
