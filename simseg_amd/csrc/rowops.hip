@@ -2,6 +2,7 @@
 // BERT embedding gather/scatter (K9), LoDA top-k pooling + L2norm fwd/bwd (K11, K12), row norms, column sums,
 // casts and transposes.  Every kernel moves 16 bytes per lane per access and reduces rows with wave shuffles.
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -867,30 +868,39 @@ inline int grid_for(long n, int block, int cap = 4096) {
 // were resident and a quarter-full second round followed.
 constexpr int LN_BWD_MAX_GRID = 2048;
 inline int ln_bwd_grid(const void* fn, int slot, size_t lds, long rows) {
-    // (one process drives one GPU; a benign race between host threads costs a repeated query, never a wrong grid: every value written is valid)
-    static int ncu = 0;              // CUs of the device, asked once (hipGetDeviceProperties is a millisecond-class call)
-    static int cached[32];           // blocks per CU of instantiation `slot` at LDS size cached_lds[slot] (0 = not asked yet)
-    static size_t cached_lds[32];
-    static int forced = -1;          // SIMSEG_LN_BWD_BLOCKS_PER_CU (tools/ln_bench.py sweeps), read once
-    if (ncu <= 0) {
-        int dev = 0, n = 256;
+    // Host threads race here (autograd runs the two towers' backward passes on two threads), and a process may drive several devices: the
+    // cache is per device, and an entry is ONE 64-bit word - (LDS bytes << 8 | blocks per CU), read and written atomically - so a reader
+    // never pairs one call's occupancy with another call's LDS size.  A lost race costs a repeated query, never a wrong grid.
+    constexpr int MAXDEV = 16;
+    static std::atomic<int> ncu[MAXDEV];                       // CUs of the device, asked once (hipGetDeviceProperties is a millisecond-class call)
+    static std::atomic<unsigned long long> cached[MAXDEV][32]; // per (device, instantiation slot)
+    static std::atomic<int> forced{-1};                        // SIMSEG_LN_BWD_BLOCKS_PER_CU (tools/ln_bench.py sweeps), read once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
+    int n_cu = ncu[dev].load(std::memory_order_relaxed);
+    if (n_cu <= 0) {
+        n_cu = 256;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-        ncu = n;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        ncu[dev].store(n_cu, std::memory_order_relaxed);
     }
-    if (forced < 0) {
+    int f = forced.load(std::memory_order_relaxed);
+    if (f < 0) {
         const char* e = getenv("SIMSEG_LN_BWD_BLOCKS_PER_CU");
         const int v = e ? atoi(e) : 0;
-        forced = v > 0 ? v : 0;
+        f = v > 0 ? v : 0;
+        forced.store(f, std::memory_order_relaxed);
     }
     const bool ok = slot >= 0 && slot < 32;
-    int per_cu = (ok && cached_lds[slot] == lds) ? cached[slot] : 0;
+    const unsigned long long ent = ok ? cached[dev][slot].load(std::memory_order_relaxed) : 0ull;
+    int per_cu = (ent != 0 && (ent >> 8) == (unsigned long long)lds) ? (int)(ent & 0xff) : 0;
     if (per_cu <= 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
-        if (ok) { cached[slot] = per_cu; cached_lds[slot] = lds; }
+        if (per_cu > 255) per_cu = 255;
+        if (ok) cached[dev][slot].store(((unsigned long long)lds << 8) | (unsigned long long)per_cu, std::memory_order_relaxed);
     }
-    if (forced > 0) per_cu = forced;
-    const long per_dev = (long)per_cu * ncu;
+    if (f > 0) per_cu = f;
+    const long per_dev = (long)per_cu * n_cu;
     const int want = grid_for(rows, 4, LN_BWD_MAX_GRID);
     return want < per_dev ? want : (int)per_dev;
 }

@@ -45,7 +45,18 @@ def crf_masks(prob, cand_idx, images_u8, chunk=None, scale=1, static=None, **par
     if chunk is None:
         # images per call: ~16.7 M pixels (64 windows of 512^2, 32 images of 512 x 1024; 17.7 GB of workspace).  Round 5, after the lattice
         # build became cheaper per image: 16 / 32 / 64 windows of 512^2 per call = 20.7 / 19.9 / 19.1 ms per 63-window batch
-        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "0")) or max(8, min(128, (1 << 24) // (H * W)))
+        chunk = int(os.environ.get("SIMSEG_CRF_CHUNK", "0"))
+        if not chunk:
+            # ... bounded by what the device has FREE: the workspace is ~1.06 KB per pixel and call (17.7 GB at 16.7 M pixels), the encoder
+            # pipeline keeps two batches in flight beside it, and a 2048^2 source image alone is 4.2 M pixels - so no floor above one image
+            budget = 1 << 24
+            if dev.type == "cuda":
+                try:
+                    free, _ = torch.cuda.mem_get_info(dev)
+                    budget = min(budget, int(0.5 * free / 1100))
+                except Exception:       # noqa: BLE001
+                    pass
+            chunk = max(1, min(128, budget // (H * W)))
     masks = torch.zeros(B, K, H, W, device=dev, dtype=torch.uint8)
     visited = (cand_idx >= 0).cpu()
     kw = dict(CRF_PARAMS, **params)
@@ -182,14 +193,14 @@ def shard_batches(batches, rank, world):
 
 
 def evaluate_sharded(model, batches, text, top_cls_num, num_classes=None, group=None, slide=None, crf=True, mean=None, std=None, sim_dtype=None,
-                     device=None, pipelined=None, window_batch=None):
+                     device=None, pipelined=None, window_batch=None, presharded=False):
     """The zero-shot segmentation evaluation over `batches` = an iterable of (image [b,3,H,W], label [b,Hl,Wl] uint8) - the SAME iterable on
     every rank - data-parallel over the ranks of `group` (default: the world, or a single process when torch.distributed is not
     initialised): batches are dealt round-robin (shard_batches; the reference's loader gives every rank every image,
     simseg/datasets/seg/seg_dataset.py:67-81), each rank accumulates its [3, C] area histograms on its device and ONE all-reduce(SUM) of that
     tensor ends the evaluation (simseg/utils/metrics.py:85-97 sums the same three vectors over the images).  Every rank still ITERATES the
-    whole iterable (a batch it skips is produced and dropped): hand in something cheap to iterate - batch descriptors, or a loader over a
-    dataset sharded with the same i % world == rank rule - when producing a batch is expensive.  slide = (win, stride): the
+    whole iterable (a batch it skips is produced and dropped): when producing a batch is expensive, hand in this rank's share only - a loader
+    over a dataset sharded with the same i % world == rank rule - and say presharded=True (tools/seg_eval_device.py does).  slide = (win, stride): the
     sliding-window form (encode_batch_sliding); None: one network input per image (encode_batch).
     -> dict(iou [C] float64, miou, hist [3,C] int64 (global), images (global count), images_local)."""
     import torch.distributed as dist
@@ -212,7 +223,7 @@ def evaluate_sharded(model, batches, text, top_cls_num, num_classes=None, group=
     count = 0
     pipe = EvalPipeline(dev, encode, finish, pipelined=crf if pipelined is None else pipelined)
     with torch.no_grad():
-        for image, label in shard_batches(batches, rank, world):
+        for image, label in (batches if presharded else shard_batches(batches, rank, world)):      # presharded: `batches` is already this rank's share
             pipe.submit(image.to(dev, non_blocking=True), label.to(dev, non_blocking=True))
             count += image.shape[0]
         pipe.flush()

@@ -21,6 +21,7 @@ import sys
 import time
 
 import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -104,17 +105,46 @@ def main():
         with torch.no_grad():
             return class_text_embeddings(model, enc["input_ids"].view(C, P, -1).to(ENV.device), enc["attention_mask"].view(C, P, -1).to(ENV.device))
 
-    def batches(name):
+    def _emit_group(group):
+        if all(l.shape == group[0][1].shape and i.shape == group[0][0].shape for i, l in group):
+            yield torch.cat([i for i, _ in group]), torch.cat([l for _, l in group])
+        else:
+            for i, l in group:
+                yield i, l
+
+    def batches(name, shard=None):
+        """shard = (rank, world): only THIS rank's batches are produced (batch i goes to rank i % world - evaluate_sharded's rule), i.e. a
+        rank decodes and transforms 1 / world of the images instead of all of them (the reference's loader gives every rank every image,
+        simseg/datasets/seg/seg_dataset.py:67-81).  Batches are formed from `--batch` consecutive dataset items; an item whose label shape
+        differs from its batch's ends the batch early in the unsharded form only - the sharded form cuts fixed groups of `--batch` items and
+        splits a group with mixed shapes into single-image batches."""
         if args.synthetic:
             g = torch.Generator().manual_seed(1)
-            for s in range(0, args.synthetic, args.batch):
+            for i, s in enumerate(range(0, args.synthetic, args.batch)):
                 b = min(args.batch, args.synthetic - s)
                 hw = (size, 2 * size) if args.slide else (size, size)        # sliding window: 1 x 3 windows at half-window stride
                 lab = torch.randint(0, 21, (b, *hw), generator=g, dtype=torch.int64).to(torch.uint8)
-                yield torch.randn(b, 3, *hw, generator=g), lab
+                img = torch.randn(b, 3, *hw, generator=g)
+                if shard is None or i % shard[1] == shard[0]:
+                    yield img, lab
             return
         from simseg.datasets.seg.seg_dataset import build_torch_valid_loader
         loader = build_torch_valid_loader(cfg, name, mode="valid")
+        if shard is not None and shard[1] > 1:
+            # the same loader over a Subset holding this rank's groups of `--batch` consecutive items
+            ds = loader.dataset
+            idx = [i for i in range(len(ds)) if (i // args.batch) % shard[1] == shard[0]]
+            loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=1, shuffle=False, num_workers=getattr(loader, "num_workers", 0),
+                                                 collate_fn=loader.collate_fn)
+            group = []
+            for image, label in loader:
+                group.append((image, label.to(torch.uint8)))
+                if len(group) == args.batch:
+                    yield from _emit_group(group)
+                    group = []
+            if group:
+                yield from _emit_group(group)
+            return
         imgs, labs = [], []
         for image, label in loader:                       # reference loader: batch size 1, labels at raw resolution
             imgs.append(image); labs.append(label.to(torch.uint8))
@@ -168,8 +198,12 @@ def main():
             # the product loop: batches dealt round-robin to the ranks of the process group (one rank when launched plainly; N under
             # `python -m torch.distributed.run --nproc-per-node N tools/seg_eval_device.py ...`), ONE all-reduce of the [3, C] area histograms
             slide = tuple(int(v) for v in args.slide.split(",")) if args.slide else None
-            res = segpost.evaluate_sharded(model, batches(name), text, top_cls_num, slide=slide, crf=not args.no_crf, mean=mean, std=std,
-                                           device=ENV.device)
+            # (each rank's loader produces only its own batches; evaluate_sharded then sees a one-rank deal of them and still ends with the
+            #  all-reduce of the histograms over the world)
+            on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            shard = (dist.get_rank(), dist.get_world_size()) if on else None
+            res = segpost.evaluate_sharded(model, batches(name, shard), text, top_cls_num, slide=slide, crf=not args.no_crf, mean=mean, std=std,
+                                           device=ENV.device, presharded=on)
             torch.cuda.synchronize()
             iou, miou, count = res["iou"], res["miou"], res["images"]
         dt = time.perf_counter() - t0
