@@ -1253,6 +1253,15 @@ template <bool DBG>
 static void launch_w64(const AttnParams& p0, hipStream_t stream, int nqb) {
     AttnParams p = p0;
     const long bh8 = ((long)(p.B * p.H + 7) / 8) * 8;
+    // Small launches (the reference tool's one image per call: 12 heads x 1025 rows = 48 + 12 blocks for 256 CUs) take the one-query-block
+    // form: 128-row blocks put more CUs to work and a lone block finishes sooner (T = 1025, 12 heads, bf16: 17.8 / 18.3 us against 22.2 / 22.4
+    // at 1 / 2 images; from 4 images on - more than 256 of its blocks - the two-block form is ahead again: tools/scratch/attn_w64_small.py).
+    // Sequences that leave a 256-row block 25-50 % full (577 tokens: 65 rows) keep it up to four rounds of blocks.
+    if (nqb == 0) {
+        const long blocks1 = (long)p.B * p.H * ((p.T + 127) / 128);
+        const int left = p.T % 256;
+        nqb = (blocks1 <= 256 || (left > 64 && left <= 128 && blocks1 <= 1024)) ? 1 : 2;
+    }
     if (nqb != 2) {
         p.gxm = p.gxw = (p.T + 127) / 128;
         if (p.qscaled) launch_w64_grid<1, true, DBG>(p, stream, (unsigned)(p.gxw * bh8));
@@ -3026,7 +3035,7 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
         if (rc) return rc;
     } else if (T >= W64_MINT && !p.mask && !p.drop_thresh && g_attn_variant != 1) {
         // 64 queries per wave, four waves per block, every block of a (batch, head) on one XCD
-        launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2);
+        launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : (g_attn_variant == 7 ? 2 : 0));
     } else
         if (p.drop_thresh) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
         else if (p.mask) hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, true, false>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
@@ -3045,7 +3054,7 @@ extern "C" int simseg_attention_fwd_qscaled(const void* qkv, void* out, float* l
     SS_CHECK(out, "attention_fwd_qscaled: null out");
     SS_CHECK(T >= W64_MINT, "attention_fwd_qscaled: sequences of at least %d tokens", W64_MINT);
     p.out = out; p.lse = lse; p.qscaled = 1;
-    launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2);
+    launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : (g_attn_variant == 7 ? 2 : 0));
     SS_LAUNCH_CHECK("attention_fwd_qscaled");
     return 0;
 }
@@ -3091,7 +3100,7 @@ extern "C" int simseg_debug_attention_timeline(const void* qkv, void* out, float
     const int nw = attn_waves_per_block(q32);
     dim3 grid((unsigned)(((q32 + nw - 1) / nw) * (((B * H + 7) / 8) * 8)));      // 1-D, see attn_block_map
     if (T >= W64_MINT && (T - 1) % 64 == 0 && g_attn_variant != 1)      // the w64 kernel's record layout: see the end of attn_fwd_w64_kernel
-        { p.qscaled = 1; launch_w64<true>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2); }      // (timing only: q taken as pre-scaled)
+        { p.qscaled = 1; launch_w64<true>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : (g_attn_variant == 7 ? 2 : 0)); }      // (timing only: q taken as pre-scaled)
     else
         hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, false, true>), grid, dim3(nw * 64), 0, (hipStream_t)stream, p);
     SS_LAUNCH_CHECK("attention_timeline");

@@ -787,10 +787,15 @@ def test_attention_fwd_long_sequences(ops, B, T, H, dtype):
     against fp32 torch on the same 16-bit operands, and against the ring kernel it replaces (variant 1)."""
     qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.3, dtype=dtype)
     want = _attn_ref(qkv, H, None, 0.125)
-    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
     tol = 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3
-    _close(out, want, tol, f"attention fwd T={T} {dtype}")
-    _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
+    for variant in (7, 6, 0):          # two query blocks per wave (+ key-split blocks), one (small launches), the dispatcher's choice
+        ops.set_attention_variant(variant)
+        try:
+            out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+        finally:
+            ops.set_attention_variant(0)
+        _close(out, want, tol, f"attention fwd T={T} {dtype} variant {variant}")
+        _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
     ops.set_attention_variant(1)
     try:
         ring, _ = ops.attention_fwd(qkv, H, None)
@@ -812,9 +817,14 @@ def test_attention_fwd_qscaled(ops, B, T, H, dtype):
     back = qkv.float().view(B, T, 3, H, 64).clone()
     back[:, :, 0] /= c
     back = back.view(B, T, 3 * H * 64)
-    out, lse = ops.attention_fwd_qscaled(qkv, H, save_lse=True)
-    _close(out, _attn_ref(back, H, None, 0.125), 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3, f"attention fwd qscaled T={T} {dtype}")
-    _close(lse, _lse_ref(back, H), 1e-5, "lse (log2)")
+    for variant in (7, 6):
+        ops.set_attention_variant(variant)
+        try:
+            out, lse = ops.attention_fwd_qscaled(qkv, H, save_lse=True)
+        finally:
+            ops.set_attention_variant(0)
+        _close(out, _attn_ref(back, H, None, 0.125), 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3, f"attention fwd qscaled T={T} {dtype} variant {variant}")
+        _close(lse, _lse_ref(back, H), 1e-5, "lse (log2)")
     with pytest.raises(Exception):
         ops.attention_fwd_qscaled(qkv[:, :300].contiguous(), H)
 
@@ -840,16 +850,25 @@ def test_attention_fwd_long_recentre_branch(ops, T, dtype):
     assert float(sc.max()) > 150.0 and float((sc.amax(-1) - sc[..., 0]).max()) > 100.0       # far above the class-token score, beyond 2^127
     want = _attn_ref(qkv, H, None, 0.125)
     tol = 1.5e-2 if dtype == torch.bfloat16 else 2.5e-3
-    out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
-    assert torch.isfinite(out.float()).all()
-    _close(out, want, tol, f"long forward with late maxima T={T}")
-    _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
+    for variant in (7, 6):
+        ops.set_attention_variant(variant)
+        try:
+            out, lse = ops.attention_fwd(qkv, H, None, save_lse=True)
+        finally:
+            ops.set_attention_variant(0)
+        assert torch.isfinite(out.float()).all()
+        _close(out, want, tol, f"long forward with late maxima T={T} variant {variant}")
+        _close(lse, _lse_ref(qkv, H), 1e-5, "lse (log2)")
+    ops.set_attention_variant(7)
     c = ops.attention_qscale(0.125)
     qs = qkv.clone()
     qs.view(B, T, 3, H, 64)[:, :, 0] = (v5[:, :, 0].float() * c).to(dtype)
     back = qs.float().view(B, T, 3, H, 64).clone()
     back[:, :, 0] /= c
-    out2, lse2 = ops.attention_fwd_qscaled(qs, H, save_lse=True)
+    try:
+        out2, lse2 = ops.attention_fwd_qscaled(qs, H, save_lse=True)
+    finally:
+        ops.set_attention_variant(0)
     _close(out2, _attn_ref(back.view(B, T, -1), H, None, 0.125), tol, f"qscaled forward with late maxima T={T}")
     _close(lse2, _lse_ref(back.view(B, T, -1), H), 1e-5, "lse (log2)")
 
