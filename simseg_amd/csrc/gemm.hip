@@ -70,8 +70,6 @@ struct GemmParams {
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the producing layer)
     int pf_next;             // ping-pong kernel: the tail's copies fetch the next tile of this XCD (see gemm_pp_kernel)
     int aux_blocked;         // act 3 / 4 on the ping-pong kernels: aux_out / aux is the tile-blocked accumulator image (simseg_gemm act codes 5 / 6)
-    int xcd_affine;          // EXPERIMENT (SIMSEG_GEMM_WGRAD_XCD=1, profiles/r6_wgrad_xcd_affine.txt): split-K on the ping-pong kernel with every K-slice of an
-                             // output tile on ONE XCD and the partial tiles added by L2-scope atomics.  Relies on the OBSERVED block -> XCD map (b % 8).
 };
 
 template <typename T> struct TT;
@@ -227,9 +225,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, const f32x16
                 for (int rr = 0; rr < 32; ++rr) {
                     const int row = row0 + rr;
                     if (row >= p.M) break;
-                    float* dst = reinterpret_cast<float*>(C) + (long)row * p.ldc + col;
-                    if (p.xcd_affine) __hip_atomic_fetch_add(dst, wlds[rr * EP_PITCH + lane] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else atomicAdd(dst, wlds[rr * EP_PITCH + lane] * p.alpha);
+                    atomicAdd(reinterpret_cast<float*>(C) + (long)row * p.ldc + col, wlds[rr * EP_PITCH + lane] * p.alpha);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1216,29 +1212,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     const int grp = wave >> 2, wn = wave & 3;
     const int tiles_n = (p.N + 255) / 256;
     const int tiles = tiles_n * ((p.M + 255) / 256);
-    const int nk = p.K / 64;
-    int kz, t, kt0, ntile;
-    if (p.xcd_affine) {
-        // XCD x (= blockIdx % 8, observed) owns the tiles x, x + 8, ...; its gridDim / 8 blocks are dealt to them as equal K-ranges
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-        const int tiles_x = tiles / 8 + (x < tiles % 8 ? 1 : 0);
-        if (tiles_x == 0) return;
-        const int z = per_xcd / tiles_x;
-        const int ti = j / z;
-        if (ti >= tiles_x) return;
-        kz = j - ti * z;
-        t = x + 8 * ti;
-        const int ks = (nk + z - 1) / z;
-        kt0 = kz * ks;
-        ntile = min(nk, kt0 + ks) - kt0;
-        if (ntile <= 0) return;
-    } else {
-        const int q = xcd_remap(blockIdx.x, gridDim.x);
-        kz = q / tiles; t = q - kz * tiles;
-        kt0 = kz * p.ksplit;
-        ntile = min(nk, kt0 + p.ksplit) - kt0;
-    }
+    const int q = xcd_remap(blockIdx.x, gridDim.x);
+    const int kz = q / tiles, t = q - kz * tiles;
     const int m0 = (t / tiles_n) * 256, n0 = (t % tiles_n) * 256;
+    const int nk = p.K / 64;
+    const int kt0 = kz * p.ksplit;
+    const int ntile = min(nk, kt0 + p.ksplit) - kt0;
     const int stot = 4 * ntile;                                      // half-tiles this block consumes
     // source of K-tile kt: base + kt * step (bytes); the per-lane parts are 32-bit offsets computed once
     const char* Ab = static_cast<const char*>(p.A) + (TA ? (long)kt0 * 64 * p.lda * 2 : (long)kt0 * 128);
@@ -1488,14 +1467,6 @@ int launch_pp(const GemmParams& p, int splitk, hipStream_t stream) {
     q.ksplit = (nk + splitk - 1) / splitk;
     const int z = (nk + q.ksplit - 1) / q.ksplit;
     q.nsplit = z;
-    static int xcd = -1;
-    if (xcd < 0) { const char* e = getenv("SIMSEG_GEMM_WGRAD_XCD"); xcd = e ? atoi(e) : 0; }
-    if (xcd && z > 1 && sizeof(TO) == 4 && tiles <= 256) {      // experiment: one block per CU, slices of a tile on one XCD, L2-scope atomics
-        q.xcd_affine = 1;
-        hipLaunchKernelGGL(kern, dim3(256, 1, 1), dim3(512), SMEM, stream, q);
-        SS_LAUNCH_CHECK("simseg_gemm(ping-pong, xcd-affine)");
-        return 0;
-    }
     hipLaunchKernelGGL(kern, dim3(tiles * z, 1, 1), dim3(512), SMEM, stream, q);
     SS_LAUNCH_CHECK("simseg_gemm(ping-pong)");
     return 0;
