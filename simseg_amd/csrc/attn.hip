@@ -3027,6 +3027,8 @@ extern "C" int simseg_attention_fwd(const void* qkv, const int64_t* key_mask, vo
         // resident kernel at the ViT-B training shape (223 vs 177 us, tools/attn_fwd_ab.py) - see the notes at the kernel
         const int rc = launch_fwd_pers(p, (hipStream_t)stream);
         if (rc) return rc;
+    } else if ((g_attn_variant == 6 || g_attn_variant == 7) && T >= 65 && !p.mask && !p.drop_thresh) {
+        launch_w64<false>(p, (hipStream_t)stream, g_attn_variant == 6 ? 1 : 2);      // tools: the long-sequence forward on a short sequence
     } else if ((T <= RES_AUTO_T || (g_attn_variant >= 2 && T <= RES_MAXT)) && g_attn_variant != 1) {
         int rc;
         if (p.drop_thresh) rc = launch_fwd_res<true, true>(p, (hipStream_t)stream);
