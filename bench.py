@@ -33,7 +33,7 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-TRAFFIC_JSON = "r5_pmc_traffic.json"
+TRAFFIC_JSON = "r6_pmc_traffic.json"
 _JSON_FD = 1        # where the one JSON line goes (main() parks the real stdout here and points fd 1 at stderr)
 
 
