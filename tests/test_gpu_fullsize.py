@@ -248,6 +248,48 @@ def test_vitb_512_window_forward_vs_oracle(monkeypatch):
     print(f"ViT-B@512 fp32 max err {err:.2e}; bf16 relative L2 error {rel16:.2e}")
 
 
+def test_vitb_512_window_qscaled_attention_path(monkeypatch):
+    """Round 6: in 16-bit evaluation at T >= 512 the ViT blocks fold scale * log2(e) into the q rows of `attn.qkv` (towers._wt_qscaled) and
+    call simseg_attention_fwd_qscaled.  (i) bf16 and fp16 outputs with the folded projection agree with the unfolded path
+    (SIMSEG_AMD_QSCALED=0: the generic entry point, q scaled by the kernel) to 16-bit noise and are as close to the fp32 oracle; (ii) the
+    folded copy is a cache keyed on the parameters' versions: an in-place update of the weight changes the output exactly as it does without
+    the fold."""
+    from oracle import simseg_ref as R
+    from simseg_amd import towers
+    from simseg_amd.nn import ViT
+    ref = R.init_weights_(R.RefViT("vit_base_patch16_224_in21k", 512), seed=15).eval()
+    m = ViT("vit_base_patch16_224_in21k", 512)
+    m.load_state_dict(ref.state_dict(), strict=False)
+    m = m.cuda().eval()
+    x = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(4))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        want = ref(x)
+        for mode, tol in (("bf16", 2e-2), ("fp16", 4e-3)):
+            monkeypatch.setenv("SIMSEG_AMD_COMPUTE", mode)
+            monkeypatch.setenv("SIMSEG_AMD_QSCALED", "1")
+            n0 = len(towers._WQS)
+            got = m(x.cuda()).float().cpu()
+            assert len(towers._WQS) >= max(n0, 12)                       # one folded copy per block
+            monkeypatch.setenv("SIMSEG_AMD_QSCALED", "0")
+            plain = m(x.cuda()).float().cpu()
+            rel, rel0 = float((got - want).norm() / want.norm()), float((plain - want).norm() / want.norm())
+            diff = float((got - plain).norm() / want.norm())
+            print(f"ViT-B@512 {mode}: relative L2 error folded {rel:.2e}, unfolded {rel0:.2e}, between them {diff:.2e}")
+            assert rel < tol and rel0 < tol and diff < tol and rel < 1.5 * rel0 + 1e-4
+        # cache invalidation: perturb block 0's qkv weight in place
+        monkeypatch.setenv("SIMSEG_AMD_COMPUTE", "bf16")
+        monkeypatch.setenv("SIMSEG_AMD_QSCALED", "1")
+        before = m(x.cuda()).float()
+        w = dict(m.named_parameters())["blocks.0.attn.qkv.weight"]
+        w.mul_(1.5)
+        after = m(x.cuda()).float()
+        monkeypatch.setenv("SIMSEG_AMD_QSCALED", "0")
+        after_plain = m(x.cuda()).float()
+        assert float((after - before).norm() / before.norm()) > 1e-2                     # the update is seen
+        assert float((after - after_plain).norm() / after_plain.norm()) < 2e-2           # and it is the same update
+
+
 def test_compact_saved_tensors_keep_the_gradient_fidelity(monkeypatch):
     """Round 4 halves three streams of the 16-bit training step: the MLP blocks save GELU' as an 8-bit tile-blocked image (simseg_gemm act 7 / 8)
     instead of a 16-bit one (act 5 / 6), the ViT blocks hand the residual-stream gradient from LayerNorm backward to LayerNorm backward
