@@ -29,8 +29,33 @@ class IndexedEmbInfo:
 
 
 class EmbANN:
-    def __init__(self, chunk_size=None):
-        raise NotImplementedError("EmbANN's sorted-gid matrices are never materialised here; use RetrievalMetric")
+    """The reference's exhaustive nearest-neighbour helper (utils.py:30-50) with its outputs: for every left row the right group ids sorted
+    by descending similarity [M, N] and the matrix of matches with the row's own id.  RetrievalMetric above never materialises these (it
+    counts strictly larger scores instead: two passes over the similarity matrix, no argsort, no int64 gather); this class is for callers
+    that want the matrices themselves.  The similarity product runs on the fp32 MFMA GEMM when the embeddings live on the GPU; equal scores
+    are ordered by column (a stable sort) where torch.argsort leaves the order unspecified.  With a chunk size the left rows go through in
+    chunks and the two outputs are concatenated (the reference's `torch.cat` of a list of TUPLES, utils.py:47-50, cannot run)."""
+
+    def __init__(self, chunk_size=None) -> None:
+        self.chunk_size = chunk_size
+
+    def _ann(self, leftemb: IndexedEmbInfo, rightemb: IndexedEmbInfo):
+        a, b = leftemb.emb_mat, rightemb.emb_mat
+        if a.is_cuda:
+            from simseg_amd import ops
+            sim = ops.gemm(a.float().contiguous(), b.float().contiguous())          # [M, N] = a . b^T
+        else:
+            sim = a.float() @ b.float().T
+        order = torch.argsort(sim, dim=1, descending=True, stable=True)
+        right_sorted = rightemb.group_idx.to(order.device)[order]                   # = gather(expand(right_gid), 1, order)
+        matched = right_sorted == leftemb.group_idx.to(order.device).unsqueeze(1)
+        return right_sorted, matched
+
+    def __call__(self, leftemb: IndexedEmbInfo, rightemb: IndexedEmbInfo):
+        if self.chunk_size is None:
+            return self._ann(leftemb, rightemb)
+        parts = [self._ann(sub, rightemb) for sub in leftemb.to_chunks(self.chunk_size)]
+        return torch.cat([p[0] for p in parts], dim=0), torch.cat([p[1] for p in parts], dim=0)
 
 
 class RetrievalMetric:

@@ -538,3 +538,30 @@ def test_gradsync_buckets_are_cut_at_stream_boundaries():
     sync._split_by_stream()
     assert [bk["members"] for bk in sync.buckets] == [bk["members"] for bk in before]
     sync.close()
+
+
+def test_embann_matrices_reproduce_the_reference_recalls():
+    """simseg.tasks.clip.hooks.utils.EmbANN (reference: utils.py:30-50) returns the sorted right-id matrix and the match matrix; fed through
+    the reference's RetrievalMetric arithmetic (first match per row -> R@1/5/10, utils.py:59-75) they give the recalls the REFERENCE produced
+    for the committed fixture - whole and in chunks (the reference's own chunked path cannot run: torch.cat of tuples)."""
+    import numpy as np
+    import torch
+    from conftest import GOLD
+    from simseg.tasks.clip.hooks.utils import EmbANN, IndexedEmbInfo
+    g = np.load(os.path.join(GOLD, "retrieval.npz"))
+    img = IndexedEmbInfo("image", torch.from_numpy(g["gid_rows"]), torch.from_numpy(g["img_rows"])).unique()
+    txt = IndexedEmbInfo("text", torch.from_numpy(g["gid_txt"]), torch.from_numpy(g["txt"]))
+
+    def recalls(matched):
+        has, first = torch.max(matched, dim=1)
+        rank = first[has]
+        return [float((rank < k).sum() / has.sum()) for k in (1, 5, 10)]
+
+    for left, right, want in ((img, txt, g["i2t"]), (txt, img, g["t2i"])):
+        ids, matched = EmbANN()(left, right)
+        assert ids.shape == (left.emb_mat.shape[0], right.emb_mat.shape[0]) and matched.dtype == torch.bool
+        np.testing.assert_allclose(recalls(matched), want, atol=1e-7)
+        sim = left.emb_mat @ right.emb_mat.T
+        assert torch.equal(ids[:, 0], right.group_idx[sim.argmax(1)])                 # best column first
+        ids_c, matched_c = EmbANN(chunk_size=37)(left, right)
+        assert torch.equal(ids_c, ids) and torch.equal(matched_c, matched)
