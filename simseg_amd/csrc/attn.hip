@@ -1243,10 +1243,16 @@ __global__ __launch_bounds__(256, NQB == 2 ? 2 : 3) void attn_fwd_w64_kernel(Att
 
 // host side.  Full blocks of 4 x 64 query rows (plus a partial one when more than half a block is left over); the rows behind them go to
 // key-split blocks of the same launch.  variant 6 (tools): one query block per wave throughout.
+thread_local int g_w64_extra_lds = 0;      // tools (attention variant 8): unused dynamic LDS per block, so that ONE block fits a CU
 template <int NQB, bool QS, bool DBG>
 static void launch_w64_grid(const AttnParams& p, hipStream_t stream, unsigned blocks) {
-    if ((p.T - 1) % 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, true, QS, DBG>), dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, false, QS, DBG>), dim3(blocks), dim3(256), 0, stream, p);
+    const int extra = g_w64_extra_lds;
+    if (extra) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_w64_kernel<NQB, false, QS, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, extra);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_w64_kernel<NQB, true, QS, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, extra);
+    }
+    if ((p.T - 1) % 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, true, QS, DBG>), dim3(blocks), dim3(256), extra, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_w64_kernel<NQB, false, QS, DBG>), dim3(blocks), dim3(256), extra, stream, p);
 }
 
 template <bool DBG>
@@ -3001,7 +3007,8 @@ extern "C" int simseg_set_attention_variant(int v) {
 #ifndef SS_HALF
     simseg_set_attention_variant_h16(v);      // the fp16 flavour keeps its own (thread-local) selector
 #endif
-    g_attn_variant = v;
+    g_w64_extra_lds = v == 8 ? 40000 : 0;     // 8 (tools/scratch/attn_w64_occ.py): the long-sequence forward at one block per CU
+    g_attn_variant = v == 8 ? 0 : v;
     return 0;
 }
 

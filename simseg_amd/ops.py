@@ -47,8 +47,8 @@ def set_gemm_variant(v):
 def set_attention_variant(v):
     """0 auto (bf16 sequences of <= 256 tokens on the resident kernels, their backward as one kernel; unmasked 16-bit sequences of >= 512
     tokens on the 64-queries-per-wave forward, small launches on its one-query-block form), 1 = always the streaming ring kernels, 3 = backward
-    as the two resident passes, 6 / 7 = the long-sequence forward with one / two query blocks per wave whatever the launch size
-    (tests / benchmarks only)."""
+    as the two resident passes, 6 / 7 = the long-sequence forward with one / two query blocks per wave whatever the launch size, 8 = auto
+    with the long-sequence forward held to ONE block per CU (the occupancy probe tools/scratch/attn_w64_occ.py)  (tests / benchmarks only)."""
     _VARIANT["attention"] = int(v)
     _push_variant("attention")
 

@@ -143,6 +143,109 @@ __global__ __launch_bounds__(1024) void k_mix(Res* out, float seed) {
     if ((threadIdx.x & 63) == 0) out[wave].cyc = t1 - t0;
 }
 
+
+// ---- the w64 attention tile as an instruction stream (round 6, second half): 32 MFMAs + 64 exp + 64 add + 32 cvt per tile and wave.
+// SHAPE 0: the kernel's four phases (8 MFMAs alone | 8 x (MFMA + 4 exp + 4 add + 2 cvt) | the same | 8 MFMAs alone);
+// SHAPE 1: uniform (32 x (MFMA + 2 exp + 2 add + 1 cvt)); SHAPE 2: two phases (16 MFMAs alone | 16 x (MFMA + 4 exp + 4 add + 2 cvt)).
+// `rot`: waves 4-7 (the second resident of each SIMD) start half a tile later in the pattern.
+// 0: 2 exp + 2 add + 1 cvt;  1: 2 exp + 1 cvt + 1 dot2;  2: 2 exp + 1 cvt;  3: 2 exp only;  4: 1 cvt + 2 add (no exp)
+template <int MIX>
+__device__ __forceinline__ void sm_unit_t(float (&v)[16], int k) {
+    if constexpr (MIX == 0)
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_cvt_pk_bf16_f32 %4, %0, %1\n"
+                     : "+v"(v[(2 * k) & 7]), "+v"(v[(2 * k + 1) & 7]), "+v"(v[8 + (k & 1)]), "+v"(v[10 + (k & 1)]), "+v"(v[12 + (k & 3)]));
+    else if constexpr (MIX == 1)
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_cvt_pk_bf16_f32 %3, %0, %1\n v_dot2c_f32_bf16 %2, %3, %4\n"
+                     : "+v"(v[(2 * k) & 7]), "+v"(v[(2 * k + 1) & 7]), "+v"(v[8 + (k & 1)]), "+v"(v[12 + (k & 3)]) : "v"(v[11]));
+    else if constexpr (MIX == 2)
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_cvt_pk_bf16_f32 %2, %0, %1\n"
+                     : "+v"(v[(2 * k) & 7]), "+v"(v[(2 * k + 1) & 7]), "+v"(v[12 + (k & 3)]));
+    else if constexpr (MIX == 3)
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n" : "+v"(v[(2 * k) & 7]), "+v"(v[(2 * k + 1) & 7]));
+    else
+        asm volatile("v_add_f32 %2, %2, %0\n v_add_f32 %3, %3, %1\n v_cvt_pk_bf16_f32 %4, %0, %1\n"
+                     : "+v"(v[(2 * k) & 7]), "+v"(v[(2 * k + 1) & 7]), "+v"(v[8 + (k & 1)]), "+v"(v[10 + (k & 1)]), "+v"(v[12 + (k & 3)]));
+}
+#ifndef SM_MIX
+#define SM_MIX 0
+#endif
+__device__ __forceinline__ void sm_unit(float (&v)[16], int k) { sm_unit_t<SM_MIX>(v, k); }
+template <int SHAPE>
+__device__ __forceinline__ void tile_half(int half, float (&v)[16], f32x16 (&acc)[4], bf16x8 a, bf16x8 b) {
+    if constexpr (SHAPE == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+            sm_unit(v, i);
+        }
+    } else if constexpr (SHAPE == 0) {
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+                sm_unit(v, 2 * i); sm_unit(v, 2 * i + 1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+                sm_unit(v, 2 * i); sm_unit(v, 2 * i + 1);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        }
+    } else {
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+                sm_unit(v, 2 * i); sm_unit(v, 2 * i + 1);
+            }
+        }
+    }
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(1024) void k_tile(Res* out, float seed, int rot) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = seed + 0.001f * i * (threadIdx.x & 7);
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed * i); b[i] = (__bf16)(seed + i); }
+    const int wave = threadIdx.x >> 6;
+    const bool second = rot && (((wave >> 2) & 1) != 0);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long t1 = t0;
+    int done = 0;
+    const unsigned long long span = 2000000ull;            // every wave runs for the same 2 M cycles: tiles completed while ALL co-run
+    if (!second) {
+#pragma unroll 1
+        while (t1 - t0 < span) { tile_half<SHAPE>(0, v, acc, a, b); asm volatile("" ::: "memory"); tile_half<SHAPE>(1, v, acc, a, b); ++done; t1 = __builtin_readcyclecounter(); }
+    } else {
+#pragma unroll 1
+        while (t1 - t0 < span) { tile_half<SHAPE>(1, v, acc, a, b); asm volatile("" ::: "memory"); tile_half<SHAPE>(0, v, acc, a, b); ++done; t1 = __builtin_readcyclecounter(); }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i] + acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i];
+    if (s == 12345.678f) out[1000].cyc = 1;
+    if ((threadIdx.x & 63) == 0) { out[wave].cyc = t1 - t0; out[32 + wave].cyc = done; }
+}
+
 static Res* d_out;
 static Res h_out[16];
 
@@ -152,12 +255,28 @@ static void run(const char* name, F launch, int waves, int per_body, const char*
     launch(waves * 64);
     hipDeviceSynchronize();
     hipMemcpy(h_out, d_out, sizeof(Res) * 16, hipMemcpyDeviceToHost);
-    printf("%-44s waves=%2d (%d/SIMD):", name, waves, (waves + 3) / 4);
+    printf("%-64s waves=%2d (%d/SIMD):", name, waves, (waves + 3) / 4);
     for (int w = 0; w < waves; w += (waves > 4 ? 4 : 1)) {
         const double cyc = (double)h_out[w].cyc / ITERS;
         printf("  w%d %.1f cyc/body = %.2f /%s", w, cyc, cyc / per_body, unit);
     }
     printf("\n");
+}
+
+template <typename F>
+static void run_tiles(const char* name, F launch, int waves) {
+    static Res h[64];
+    hipMemset(d_out, 0, sizeof(Res) * 1024);
+    launch(waves * 64);
+    hipDeviceSynchronize();
+    hipMemcpy(h, d_out, sizeof(Res) * 64, hipMemcpyDeviceToHost);
+    double per_simd = 0;       // tiles per cycle on SIMD 0 (waves 0, 4, 8, 12)
+    printf("%-64s waves=%2d (%d/SIMD):", name, waves, (waves + 3) / 4);
+    for (int w = 0; w < waves; w += 4) {
+        per_simd += (double)h[32 + w].cyc / (double)h[w].cyc;
+        printf("  w%d %.0f cyc/tile", w, (double)h[w].cyc / (double)h[32 + w].cyc);
+    }
+    printf("  => %.0f cycles per tile and SIMD = %.3f of the matrix pipe (1024)\n", 1.0 / per_simd, 1024.0 * per_simd);
 }
 
 int main() {
@@ -184,6 +303,17 @@ int main() {
     run("split: w0-3 mfma | w4-7 exp", [&](int n) { hipLaunchKernelGGL((k_plain<4, 0>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, 1); }, 8, 8, "body-unit(8)");
     run("split: w0-3 mfma | w4-7 fma", [&](int n) { hipLaunchKernelGGL((k_plain<4, 1>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, 1); }, 8, 8, "body-unit(8)");
     run("split: w0-3 exp  | w4-7 fma", [&](int n) { hipLaunchKernelGGL((k_plain<0, 1>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, 1); }, 8, 16, "instr");
+    // the attention tile as a stream: cycles per tile and wave; the matrix pipe needs 32 x 32 = 1024 per wave-tile
+    printf("softmax unit per MFMA pair: mix %d\n", SM_MIX);
+    for (int waves : {4, 8, 12, 16}) {
+        for (int rot : {0, 1}) {
+            if (waves == 4 && rot) continue;
+            std::string tag = std::string(rot ? " (second resident half a tile behind)" : "");
+            run_tiles(("tile, four phases" + tag).c_str(), [&](int n) { hipLaunchKernelGGL((k_tile<0>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, rot); }, waves);
+            run_tiles(("tile, uniform" + tag).c_str(), [&](int n) { hipLaunchKernelGGL((k_tile<1>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, rot); }, waves);
+            run_tiles(("tile, two phases" + tag).c_str(), [&](int n) { hipLaunchKernelGGL((k_tile<2>), dim3(1), dim3(n), 0, 0, d_out, 0.5f, rot); }, waves);
+        }
+    }
     hipFree(d_out);
     return 0;
 }
