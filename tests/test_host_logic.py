@@ -460,6 +460,40 @@ def test_layernorm_backward_kernels_fit_four_waves_per_simd():
     assert {(o, f, c) for o in ("rowops.o", "rowops_h16.o") for f in (False, True) for c in (2, 3)} <= seen, seen
 
 
+def test_long_sequence_attention_forward_register_budget():
+    """Code-object metadata of the built attn.o / attn_h16.o: the 64-queries-per-wave forward (attn_fwd_w64_kernel) sits AT its register budget
+    (256 per wave = two waves per SIMD) and its register allocation is fragile - a second inlined tile loop, a branch inside the tile body or
+    loop-invariant addresses kept live each put scratch reloads inside the tile loop, where they wait for the K / V copies in flight (DESIGN.md
+    7.1).  The production instantiations (two query blocks per wave, no masked last tile) keep <= 4 spilled registers, all outside the loop; the
+    masked-last-tile ones <= 16; the one-query-block forms (three waves per SIMD: 168 registers) spill nothing."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    seen = set()
+    for obj in ("attn.o", "attn_h16.o"):
+        path = os.path.join(REPO, "simseg_amd", "build", obj)
+        if not os.path.exists(path):
+            pytest.skip("simseg_amd/build/*.o not present (the library was built elsewhere)")
+        for name, vgpr, spill, scratch, lds in kr.kernel_resources(path):
+            m = re.search(r"attn_fwd_w64_kernel<(\d), (true|false), (true|false), (true|false)>", name)
+            if not m:
+                continue
+            nqb, edge, dbg = int(m.group(1)), m.group(2) == "true", m.group(4) == "true"
+            if dbg:
+                continue                                   # (the instrumented timeline build: tools only)
+            seen.add((obj, nqb, edge))
+            assert lds == 3 * 16384, (obj, name, lds)      # three 16-KiB stages: two (three) blocks per CU
+            if nqb == 1:
+                assert vgpr <= 168 and spill == 0 and scratch == 0, (obj, name, vgpr, spill, scratch)
+            else:
+                assert vgpr <= 256 and spill <= (16 if edge else 4) and scratch <= (64 if edge else 16), (obj, name, vgpr, spill, scratch)
+    assert {(o, n, e) for o in ("attn.o", "attn_h16.o") for n in (1, 2) for e in (False, True)} <= seen, seen
+
+
 def test_gradsync_zero_copy_targets():
     """GradSync.begin() arms the zero-copy path: a backward function that accumulates its weight gradient into towers._grad_target(param)
     (a fresh, zero-filled view of the exchange buffer) hands autograd a tensor it ADOPTS as .grad - the bucket hand-over then copies
