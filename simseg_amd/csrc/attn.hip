@@ -1546,7 +1546,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             union { u32x4 v; bf16x8 hh; } u;      // (queries >= T: row T-1, never stored - an unconditional request needs no wait of its own)
-            u.v = *reinterpret_cast<const u32x4*>(base + (long)min(q, T - 1) * RS + (2 * kk + h2) * 8);
+            // (uniform base + a 32-bit lane offset: as a 64-bit per-lane pointer the second pass's address lived in a spilled register pair)
+            const unsigned voff = ((unsigned)min(q, T - 1) * (unsigned)RS + (unsigned)((2 * kk + h2) * 8)) * 2u;
+            u.v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + voff);
             qr[kk] = u.hh;
         }
     };
