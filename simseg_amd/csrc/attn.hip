@@ -879,14 +879,13 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
     };
     if (DBG) dt0 = dbg_start;
 
-    // tiles 0 and 1 on their way first; Q, k_0, v_0 behind them
+    // Q, k_0, v_0 requested first, the copies of tiles 0 and 1 right behind them: the requests complete in order, so the prologue's arithmetic
+    // (offset tuple, O = v_0) waits for its own operands only and runs while the tiles land
     const int rs_bytes = (int)RS * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, T * rs_bytes - h * 128, 0x00020000);
     const int drow = lane >> 3;                     // row within an 8-row piece; k_swz / v_swz of the row depend on the lane only
     const int offK = drow * rs_bytes + HD * 2 + (((lane & 7) ^ ((lane >> 4) & 3) ^ ((wave & 1) << 2)) << 4);
     const int offV = drow * rs_bytes + HD * 4 + (((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4);
-    if (nt > 0) w64_dma(rsrc, offK, offV, 1, rs_bytes, lds, wave);
-    if (nt > 1) w64_dma(rsrc, offK, offV, 1 + KT, rs_bytes, lds + GSTAGE, wave);
     bf16x8 qr[NQB][4];                              // QS: the projection's q columns carry scale * log2(e) (simseg_attention_fwd_qscaled)
     const float cexp = QS ? 1.0f : p.scale_log2e;   // what an exponent is multiplied by in front of the v_exp
     f32x16 o[NQB][2];                               // [query block][d block], unnormalised
@@ -908,6 +907,8 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) v0[db][r4] = *reinterpret_cast<const bf16x4*>(base + 2 * HD + db * 32 + 8 * r4 + 4 * h2);
+        if (nt > 0) w64_dma(rsrc, offK, offV, 1, rs_bytes, lds, wave);
+        if (nt > 1) w64_dma(rsrc, offK, offV, 1 + KT, rs_bytes, lds + GSTAGE, wave);
         // key 0 opens the softmax: m = s_0, p_0 = 1, l = 1, O = v_0.  The offset tuple -s_0 comes out of the matrix pipe: an A fragment whose 32
         // rows all hold -k_0 gives every register of the result this lane's -q.k_0 (the dot product in VALU instructions took ~300 of them
         // per wave and 2 k cycles of every block's prologue)
@@ -934,7 +935,6 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
                 for (int r = 0; r < 16; ++r) o[qb][db][r] = part == 0 ? (float)v0[db][r >> 2][r & 3] : 0.f;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(0, o[NQB - 1][1][15]);
     const int a16 = lane & 15, g16 = (lane >> 4) & 1;
     const int krow = ql * 128, ksw = k_swz(ql);
@@ -943,7 +943,7 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
     int cur = 0;
     auto tile = [&](int it, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        if (it > 0) wait_vm_dyn(it + 1 < nt ? per : 0);
+        wait_vm_dyn(it + 1 < nt ? per : 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(5, 0.f);
         __builtin_amdgcn_s_barrier();
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void w64_block(const AttnParams& p, char* lds, int bh
     // the key-split form of a tile (underfilled last blocks): this wave's key block only - scores, softmax, PV in sequence
     auto tile_split = [&](int it, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        if (it > 0) wait_vm_dyn(it + 1 < nt ? per : 0);
+        wait_vm_dyn(it + 1 < nt ? per : 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
