@@ -779,11 +779,13 @@ def _lse_ref(qkv, H, scale=0.125):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,T,H", [(3, 512, 2), (2, 513, 3), (2, 577, 2), (3, 600, 3), (11, 1025, 1), (1, 1024, 3), (2, 1089, 2), (1, 1153, 2), (1, 2305, 1)])
+@pytest.mark.parametrize("B,T,H", [(3, 512, 2), (2, 513, 3), (1, 576, 3), (2, 577, 2), (3, 600, 3), (11, 1025, 1), (1, 1024, 3), (2, 1072, 2), (2, 1089, 2), (1, 1153, 2),
+                                   (1, 2305, 1)])
 def test_attention_fwd_long_sequences(ops, B, T, H, dtype):
     """The 64-queries-per-wave forward (T >= 512, no mask / dropout; csrc/attn.hip attn_fwd_w64_kernel): class-token key as the softmax's
     start, full tiles from key 1, the masked last tile ((T - 1) % 64 != 0), blocks with idle waves, the key-split block for <= 64 leftover
-    rows (513, 577 -> one main block more; 1025, 1089, 2305 -> key-split), (batch x head) counts that are not multiples of the 8 XCDs -
+    rows (513, 1025, 2305: one row; 576, 1072: both row groups of the key-split block in use; 577, 1089 -> one main block more), (batch x head)
+    counts that are not multiples of the 8 XCDs -
     against fp32 torch on the same 16-bit operands, and against the ring kernel it replaces (variant 1)."""
     qkv = _rand(B, T, 3 * H * 64, seed=T, scale=1.3, dtype=dtype)
     want = _attn_ref(qkv, H, None, 0.125)
